@@ -1,0 +1,487 @@
+// Implicit-GEMM convolution / GEMM family on the gfx950 FP32-input matrix cores.
+//
+//   gemm_fwd_kernel  : C[M,N] = act(gather(A)[M,K] . B^T + bias + addend)    (forward conv, data gradient,
+//                      nn.Linear, batched q.k^T / p.v)
+//   wgrad_kernel     : C[M,N] = sum_r A[r][M] * gather(B)[r][N]               (weight gradients, P^T.dO, dS^T.Q)
+//
+// Both use v_mfma_f32_32x32x2_f32 (exact f32 fma chain; 64 cycles/SIMD each) on 32x32 register tiles.
+// A wave's A/B fragments come from LDS; because the MFMA k-index only has to agree between A and B,
+// lane (i, h) reads ONE float4 = k {4h..4h+3} of its row and feeds element j to MFMA j (4 MFMAs per
+// pair of ds_read_b128).  Activations are channels-last so a tap's channel run is contiguous: the
+// gather is done while staging global -> registers -> LDS, never as an im2col buffer.
+#include "common.h"
+
+#define BK 32
+#define LDS_PITCH (BK + 4)   // floats; 144-byte rows keep the ds_read_b128 lane groups conflict-free
+
+struct GemmArgs {
+    const float* A; const float* B; float* C; const float* bias; const float* addend;
+    int64_t lda, ldb, ldc, ld_add;
+    int M, N, K, Cs4, act, b_layout, Zi;
+    int64_t sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
+    DevGeom g;
+};
+
+template <int BM, int BN, int WM, int WN, int VEC>
+__global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AI = BM / 32, BI = BN / 32;      // float4 chunks per thread per K tile
+    __shared__ __attribute__((aligned(16))) float As[BM * LDS_PITCH];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_PITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const uint32_t tiles_n = (p.N + BN - 1) / BN;
+    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int z = blockIdx.z, zo = z / p.Zi, zi = z - zo * p.Zi;
+    const float* __restrict__ A = p.A + zo * p.sA_o + zi * p.sA_i;
+    const float* __restrict__ B = p.B + zo * p.sB_o + zi * p.sB_i;
+    float* __restrict__ C = p.C + zo * p.sC_o + zi * p.sC_i;
+
+    // ---- per-thread staging roles: A chunk column kc (fixed), rows ar + 32*i
+    const int kc = tid & 7, ar = tid >> 3;
+    int64_t a_base[AI];
+    uint32_t a_pack[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        int row = m0 + ar + 32 * i;
+        if (row < p.M) {
+            if (p.g.is_gemm) {
+                a_base[i] = (int64_t)row * p.lda;
+                a_pack[i] = 0;
+            } else {
+                uint32_t n, pk;
+                decode_row((uint32_t)row, p.g, n, pk);
+                a_base[i] = (int64_t)n * p.g.sample_pitch;
+                a_pack[i] = pk;
+            }
+        } else {
+            a_base[i] = 0;
+            a_pack[i] = 0xFFFFFFFFu;
+        }
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[AI], rb[BI];
+    const int nk = (p.K + BK - 1) / BK;
+
+    auto load_tile = [&](int kt) {
+        // ---------------- A (gathered) ----------------
+        const int q = kt * 8 + kc;          // global float4 chunk index along K
+        const int k = q * 4;
+        bool kin = k < p.K;
+        if constexpr (VEC == 4) {
+            int tap = 0, c = k, td = 0, th = 0, tw = 0;
+            if (!p.g.is_gemm && kin) {
+                tap = q / p.Cs4;
+                c = (q - tap * p.Cs4) * 4;
+                td = (int)fdiv((uint32_t)tap, p.g.dKhw);
+                int rem = tap - td * (int)p.g.dKhw.d;
+                th = (int)fdiv((uint32_t)rem, p.g.dKw);
+                tw = rem - th * (int)p.g.dKw.d;
+            }
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (kin && a_pack[i] != 0xFFFFFFFFu) {
+                    if (p.g.is_gemm) {
+                        v = *reinterpret_cast<const f32x4*>(A + a_base[i] + k);
+                    } else {
+                        int vox;
+                        if (gather_voxel(a_pack[i], td, th, tw, p.g, vox))
+                            v = *reinterpret_cast<const f32x4*>(A + a_base[i] + (int64_t)vox * p.lda + c);
+                    }
+                }
+                ra[i] = v;
+            }
+        } else {   // Cs == 1 (the stem): the 4 k's of a chunk are 4 different taps, scalar gathers
+            int td[4], th[4], tw[4];
+            bool tok[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int tap = k + e;
+                tok[e] = tap < p.g.ntaps;
+                td[e] = (int)fdiv((uint32_t)tap, p.g.dKhw);
+                int rem = tap - td[e] * (int)p.g.dKhw.d;
+                th[e] = (int)fdiv((uint32_t)rem, p.g.dKw);
+                tw[e] = rem - th[e] * (int)p.g.dKw.d;
+            }
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (kin && a_pack[i] != 0xFFFFFFFFu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int vox;
+                        if (tok[e] && gather_voxel(a_pack[i], td[e], th[e], tw[e], p.g, vox))
+                            v[e] = A[a_base[i] + (int64_t)vox * p.lda];
+                    }
+                }
+                ra[i] = v;
+            }
+        }
+        // ---------------- B ----------------
+        if (p.b_layout == 0) {              // [N][K]
+#pragma unroll
+            for (int i = 0; i < BI; ++i) {
+                int n = n0 + ar + 32 * i;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (kin && n < p.N) v = *reinterpret_cast<const f32x4*>(B + (int64_t)n * p.ldb + k);
+                rb[i] = v;
+            }
+        } else {                            // [K][N]: float4 along n
+            constexpr int CN = BN / 4;
+#pragma unroll
+            for (int i = 0; i < BI; ++i) {
+                int cidx = tid + 256 * i;
+                int nc = cidx % CN, kk = cidx / CN;
+                int kg = kt * BK + kk, n = n0 + nc * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (kg < p.K && n < p.N) v = *reinterpret_cast<const f32x4*>(B + (int64_t)kg * p.ldb + n);
+                rb[i] = v;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(ar + 32 * i) * LDS_PITCH + kc * 4]) = ra[i];
+        if (p.b_layout == 0) {
+#pragma unroll
+            for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(ar + 32 * i) * LDS_PITCH + kc * 4]) = rb[i];
+        } else {
+            constexpr int CN = BN / 4;
+#pragma unroll
+            for (int i = 0; i < BI; ++i) {
+                int cidx = tid + 256 * i;
+                int nc = cidx % CN, kk = cidx / CN;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bs[(nc * 4 + e) * LDS_PITCH + kk] = rb[i][e];
+            }
+        }
+    };
+
+    const int frow = lane & 31, fk = (lane >> 5) * 4;
+    load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < nk) load_tile(kt + 1);      // global loads fly while the MFMAs run
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const f32x4*>(&As[((wm * TM + i) * 32 + frow) * LDS_PITCH + kk * 8 + fk]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * TN + j) * 32 + frow) * LDS_PITCH + kk * 8 + fk]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+        if (col >= p.N) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (p.addend) v += p.addend[(int64_t)row * p.ld_add + col];
+                if (p.act == CORRIF_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (p.act == CORRIF_ACT_GELU) v = gelu_erf(v);
+                C[(int64_t)row * p.ldc + col] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int VEC = 4>
+static int launch_fwd(const GemmArgs& a, int Z, hipStream_t s) {
+    uint32_t tiles = (uint32_t)((a.M + BM - 1) / BM) * (uint32_t)((a.N + BN - 1) / BN);
+    dim3 grid(tiles, 1, Z);
+    hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC>), grid, dim3(256), 0, s, a);
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}
+
+extern "C" int corrif_gemm_fwd(const CorrifGemm* p, void* stream) {
+    if (!p || !p->A || !p->B || !p->C) return CORRIF_EINVAL;
+    if (p->M <= 0 || p->N <= 0 || p->K <= 0 || p->Z < 1 || p->Zi < 1) return CORRIF_EINVAL;
+    const bool scalar = p->Cs == 1;
+    if (p->Cs <= 0 || (p->K & 3) || (p->ldb & 3)) return CORRIF_EUNSUPPORTED;
+    if (!scalar && ((p->Cs & 3) || (p->lda & 3) || ((uintptr_t)p->A & 15) || (p->sA_o & 3) || (p->sA_i & 3) ||
+                    (p->g.src_batch_pitch & 3)))
+        return CORRIF_EUNSUPPORTED;
+    if (scalar && (p->g.is_gemm || p->b_layout != 0)) return CORRIF_EUNSUPPORTED;
+    if (((uintptr_t)p->B & 15)) return CORRIF_EUNSUPPORTED;
+    if ((p->sB_o & 3) || (p->sB_i & 3)) return CORRIF_EUNSUPPORTED;
+    if (p->b_layout == 1 && (p->N & 3)) return CORRIF_EUNSUPPORTED;
+    if (p->b_layout != 0 && p->b_layout != 1) return CORRIF_EINVAL;
+    if (!geom_ok(p->g)) return CORRIF_EINVAL;
+    if (!p->g.is_gemm && !scalar && p->K != p->g.kd * p->g.kh * p->g.kw * p->Cs) return CORRIF_EINVAL;
+    if (scalar && (p->g.ntaps <= 0 || p->g.ntaps > p->g.kd * p->g.kh * p->g.kw || p->K < p->g.ntaps)) return CORRIF_EINVAL;
+    if (p->Z > 65535) return CORRIF_EUNSUPPORTED;
+    GemmArgs a;
+    a.A = p->A; a.B = p->B; a.C = p->C; a.bias = p->bias; a.addend = p->addend;
+    a.lda = p->lda; a.ldb = p->ldb; a.ldc = p->ldc; a.ld_add = p->ld_add;
+    a.M = p->M; a.N = p->N; a.K = p->K; a.Cs4 = p->Cs / 4; a.act = p->act; a.b_layout = p->b_layout; a.Zi = p->Zi;
+    a.sA_o = p->sA_o; a.sA_i = p->sA_i; a.sB_o = p->sB_o; a.sB_i = p->sB_i; a.sC_o = p->sC_o; a.sC_i = p->sC_i;
+    a.g = make_devgeom(p->g, p->lda);
+    hipStream_t s = (hipStream_t)stream;
+    if (scalar) return launch_fwd<128, 64, 2, 2, 1>(a, p->Z, s);
+    if (p->N <= 32) return launch_fwd<256, 32, 4, 1>(a, p->Z, s);
+    if (p->N <= 64) return launch_fwd<128, 64, 2, 2>(a, p->Z, s);
+    return launch_fwd<128, 128, 2, 2>(a, p->Z, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// W-type: contraction over rows.  LDS tiles are [32 rows][BM] and [32 rows][BN]; MFMA lane (i, h)
+// reads element [2s+h][i] of each (ds_read_b32, lanes consecutive -> conflict free).
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* A; const float* B; float* C; float* ws;
+    int64_t lda, ldb, ldc;
+    int R, M, N, Cs, splits, rows_per_split, Zi;
+    int64_t sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
+    DevGeom g;
+};
+
+template <int BM, int BN, int WM, int WN, int VEC>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int PA = BM + 4, PB = BN + 4;
+    constexpr int CA = BM / 4, CB = BN / 4;            // float4 chunks per row
+    constexpr int AI = 32 * CA / 256, BI = 32 * CB / 256;
+    static_assert(AI >= 1 && BI >= 1, "tile too small");
+    __shared__ __attribute__((aligned(16))) float As[32 * PA];
+    __shared__ __attribute__((aligned(16))) float Bs[32 * PB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const uint32_t tiles_n = (p.N + BN - 1) / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    int split = 0, z = 0;
+    if (p.splits > 1) split = blockIdx.z; else z = blockIdx.z;
+    const int zo = z / p.Zi, zi = z - zo * p.Zi;
+    const float* __restrict__ A = p.A + zo * p.sA_o + zi * p.sA_i;
+    const float* __restrict__ B = p.B + zo * p.sB_o + zi * p.sB_i;
+    const int r_begin = split * p.rows_per_split;
+    const int r_end = min(p.R, r_begin + p.rows_per_split);
+
+    // B staging role: column chunk jc fixed per thread -> tap / channel decode once
+    const int jc = tid % CB, br = tid / CB;              // rows br + (256/CB)*i
+    const int j = n0 + jc * 4;
+    const bool jin = j < p.N;
+    int td[VEC == 1 ? 4 : 1], th[VEC == 1 ? 4 : 1], tw[VEC == 1 ? 4 : 1], cch = j;
+    bool tok[VEC == 1 ? 4 : 1];
+    td[0] = th[0] = tw[0] = 0;
+    tok[0] = true;
+    if (!p.g.is_gemm && jin) {
+#pragma unroll
+        for (int e = 0; e < (VEC == 1 ? 4 : 1); ++e) {
+            int tap = (VEC == 1) ? j + e : j / p.Cs;
+            if (VEC != 1) cch = j - tap * p.Cs;
+            tok[e] = (VEC != 1) || tap < p.g.ntaps;
+            td[e] = (int)fdiv((uint32_t)tap, p.g.dKhw);
+            int rem = tap - td[e] * (int)p.g.dKhw.d;
+            th[e] = (int)fdiv((uint32_t)rem, p.g.dKw);
+            tw[e] = rem - th[e] * (int)p.g.dKw.d;
+        }
+    }
+    const int ac = tid % CA, arow = tid / CA;
+    const int am = m0 + ac * 4;
+    const bool ain = am < p.M;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+    f32x4 ra[AI], rb[BI];
+    auto load_tile = [&](int r0) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            int row = r0 + arow + (256 / CA) * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ain && row < r_end) v = *reinterpret_cast<const f32x4*>(A + (int64_t)row * p.lda + am);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            int row = r0 + br + (256 / CB) * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (jin && row < r_end) {
+                if (p.g.is_gemm) {
+                    v = *reinterpret_cast<const f32x4*>(B + (int64_t)row * p.ldb + j);
+                } else {
+                    uint32_t n, pk;
+                    int vox;
+                    decode_row((uint32_t)row, p.g, n, pk);
+                    if constexpr (VEC == 4) {
+                        if (gather_voxel(pk, td[0], th[0], tw[0], p.g, vox))
+                            v = *reinterpret_cast<const f32x4*>(B + (int64_t)n * p.g.sample_pitch + (int64_t)vox * p.ldb + cch);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (tok[e] && gather_voxel(pk, td[e], th[e], tw[e], p.g, vox))
+                                v[e] = B[(int64_t)n * p.g.sample_pitch + (int64_t)vox * p.ldb];
+                    }
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(arow + (256 / CA) * i) * PA + ac * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(br + (256 / CB) * i) * PB + jc * 4]) = rb[i];
+    };
+
+    const int fi = lane & 31, fh = lane >> 5;
+    if (r_begin < r_end) {
+        load_tile(r_begin);
+        for (int r0 = r_begin; r0 < r_end; r0 += 32) {
+            store_tile();
+            __syncthreads();
+            if (r0 + 32 < r_end) load_tile(r0 + 32);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = As[(2 * s + fh) * PA + (wm * TM + i) * 32 + fi];
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) b[jj] = Bs[(2 * s + fh) * PB + (wn * TN + jj) * 32 + fi];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jj], acc[i][jj], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+
+    float* __restrict__ C;
+    int64_t ldc;
+    if (p.splits > 1) { C = p.ws + (int64_t)split * p.M * p.N; ldc = p.N; }
+    else { C = p.C + zo * p.sC_o + zi * p.sC_i; ldc = p.ldc; }
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj) {
+        const int col = n0 + (wn * TN + jj) * 32 + (lane & 31);
+        if (col >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < p.M) C[(int64_t)row * ldc + col] = acc[i][jj][r];
+            }
+    }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t n, int count,
+                                   int N, int64_t ldc) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int j = 0; j < count; ++j) s += ws[(int64_t)j * n + i];
+    if (N > 0) { int64_t r = i / N; out[r * ldc + (i - r * N)] = s; }
+    else out[i] = s;
+}
+
+static int pick_splits(int R, int M, int N, int BM, int BN) {
+    int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int64_t want = (2048 + tiles - 1) / tiles;
+    int64_t maxs = R / 256;                 // at least 8 K-tiles of work per split
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    if (want > 4096) want = 4096;
+    return (int)want;
+}
+static void wgrad_tile(int M, int& BM, int& BN) { BN = 128; BM = (M <= 32) ? 32 : 64; }
+
+extern "C" size_t corrif_wgrad_workspace(const CorrifWgrad* p) {
+    if (!p || p->splits <= 1) return 0;
+    return (size_t)p->splits * (size_t)p->M * (size_t)p->N * sizeof(float);
+}
+extern "C" int corrif_wgrad_plan(int32_t R, int32_t M, int32_t N) {
+    int BM, BN;
+    wgrad_tile(M, BM, BN);
+    return pick_splits(R, M, N, BM, BN);
+}
+
+extern "C" int corrif_slab_reduce(const float* ws, float* out, int64_t n, int32_t count, void* stream) {
+    if (!ws || !out || n <= 0 || count <= 0) return CORRIF_EINVAL;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, out, n,
+                       count, 0, (int64_t)0);
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}
+
+extern "C" int corrif_wgrad(const CorrifWgrad* p, void* stream) {
+    if (!p || !p->A || !p->B || !p->C) return CORRIF_EINVAL;
+    if (p->R <= 0 || p->M <= 0 || p->N <= 0 || p->splits < 1 || p->Z < 1 || p->Zi < 1) return CORRIF_EINVAL;
+    const bool scalar = p->Cs == 1;
+    if ((p->M & 3) || (p->N & 3) || p->Cs <= 0 || (p->lda & 3)) return CORRIF_EUNSUPPORTED;
+    if (!scalar && ((p->Cs & 3) || (p->ldb & 3) || ((uintptr_t)p->B & 15) || (p->sB_o & 3) || (p->sB_i & 3) ||
+                    (p->g.src_batch_pitch & 3)))
+        return CORRIF_EUNSUPPORTED;
+    if (scalar && p->g.is_gemm) return CORRIF_EUNSUPPORTED;
+    if (((uintptr_t)p->A & 15) || (p->sA_o & 3) || (p->sA_i & 3)) return CORRIF_EUNSUPPORTED;
+    if (p->splits > 1 && (p->Z != 1 || !p->ws)) return CORRIF_EINVAL;
+    if (!geom_ok(p->g)) return CORRIF_EINVAL;
+    if (!p->g.is_gemm && !scalar && p->N != p->g.kd * p->g.kh * p->g.kw * p->Cs) return CORRIF_EINVAL;
+    if (scalar && (p->g.ntaps <= 0 || p->g.ntaps > p->g.kd * p->g.kh * p->g.kw || p->N < p->g.ntaps)) return CORRIF_EINVAL;
+    if (p->Z > 65535 || p->splits > 65535) return CORRIF_EUNSUPPORTED;
+    WgradArgs a;
+    a.A = p->A; a.B = p->B; a.C = p->C; a.ws = p->ws;
+    a.lda = p->lda; a.ldb = p->ldb; a.ldc = p->ldc;
+    a.R = p->R; a.M = p->M; a.N = p->N; a.Cs = p->Cs; a.splits = p->splits; a.Zi = p->Zi;
+    int rps = (p->R + p->splits - 1) / p->splits;
+    a.rows_per_split = (rps + 31) / 32 * 32;
+    a.sA_o = p->sA_o; a.sA_i = p->sA_i; a.sB_o = p->sB_o; a.sB_i = p->sB_i; a.sC_o = p->sC_o; a.sC_i = p->sC_i;
+    a.g = make_devgeom(p->g, p->ldb);
+    hipStream_t s = (hipStream_t)stream;
+    int BM, BN;
+    wgrad_tile(p->M, BM, BN);
+    uint32_t tiles = (uint32_t)((p->M + BM - 1) / BM) * (uint32_t)((p->N + BN - 1) / BN);
+    dim3 grid(tiles, 1, p->splits > 1 ? p->splits : p->Z);
+    if (scalar) {
+        grid.x = (uint32_t)((p->M + 63) / 64) * (uint32_t)((p->N + 127) / 128);
+        hipLaunchKernelGGL((wgrad_kernel<64, 128, 2, 2, 1>), grid, dim3(256), 0, s, a);
+    } else if (BM == 32) hipLaunchKernelGGL((wgrad_kernel<32, 128, 1, 4, 4>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_kernel<64, 128, 2, 2, 4>), grid, dim3(256), 0, s, a);
+    CORRIF_CHECK_LAUNCH();
+    if (p->splits > 1) {
+        int64_t n = (int64_t)p->M * p->N;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->ws, p->C, n, p->splits,
+                           p->N, p->ldc);
+        CORRIF_CHECK_LAUNCH();
+    }
+    return CORRIF_OK;
+}

@@ -1,0 +1,492 @@
+// BatchNorm3d / InstanceNorm3d (channels-last, statistics over rows) and LayerNorm, forward + backward.
+// HBM-bound: every pass streams float4 per lane; per-channel partial sums are kept in double so that the
+// one-pass E[x^2]-E[x]^2 variance loses nothing to cancellation; partials are combined in a fixed order
+// (deterministic, no atomics).
+#include "common.h"
+
+struct NormGeo {
+    int C4;          // float4 chunks per row
+    int CT;          // chunks per block tile  (min(C4,256))
+    int RL;          // row lanes per block    (256/CT)
+    int ctiles;      // ceil(C4/CT)
+    int chunks;      // row chunks per group
+    int64_t rows_per_chunk;
+};
+static NormGeo norm_geo(int64_t rows_per_group, int G, int C) {
+    NormGeo n;
+    n.C4 = C / 4;
+    n.CT = n.C4 < 256 ? n.C4 : 256;
+    n.RL = 256 / n.CT;
+    n.ctiles = (n.C4 + n.CT - 1) / n.CT;
+    int64_t want = 2048 / ((int64_t)G * n.ctiles);
+    if (want < 1) want = 1;
+    int64_t maxc = (rows_per_group + 4 * n.RL - 1) / (4 * n.RL);   // >= 4 rows per row lane
+    if (maxc < 1) maxc = 1;
+    n.chunks = (int)(want < maxc ? want : maxc);
+    n.rows_per_chunk = (rows_per_group + n.chunks - 1) / n.chunks;
+    return n;
+}
+extern "C" size_t corrif_norm_workspace(int64_t rows_per_group, int32_t G, int32_t C) {
+    NormGeo n = norm_geo(rows_per_group, G, C);
+    return (size_t)G * n.chunks * C * 2 * sizeof(double) + (size_t)G * C * 2 * sizeof(float) + 64;
+}
+
+// partial[(g*chunks + chunk)*C*2 + c*2 + {0,1}]
+template <int MODE>   // 0: sum x', sum x'^2 ; 1: sum g, sum g*xhat
+__global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
+                                                           int64_t lddy, const float* __restrict__ y, int64_t ldy,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           double* __restrict__ part, int64_t rows_per_group, int C, int flags,
+                                                           NormGeo n) {
+    __shared__ double red[256 * 8];
+    const int tid = threadIdx.x;
+    const int cl = tid % n.CT, rl = tid / n.CT;
+    const int chunk = blockIdx.x, ct = blockIdx.y, g = blockIdx.z;
+    const int c4 = ct * n.CT + cl;
+    const bool active = (rl < n.RL) && (c4 < n.C4);
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    if (active) {
+        const int64_t r0 = (int64_t)chunk * n.rows_per_chunk;
+        int64_t r1 = r0 + n.rows_per_chunk;
+        if (r1 > rows_per_group) r1 = rows_per_group;
+        const int64_t gbase = (int64_t)g * rows_per_group;
+        f32x4 mu = {0, 0, 0, 0}, rs = {1, 1, 1, 1};
+        if (MODE == 1) {
+            mu = *reinterpret_cast<const f32x4*>(mean + (int64_t)g * C + c4 * 4);
+            rs = *reinterpret_cast<const f32x4*>(rstd + (int64_t)g * C + c4 * 4);
+        }
+        for (int64_t r = r0 + rl; r < r1; r += n.RL) {
+            const int64_t row = gbase + r;
+            f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ldx + c4 * 4);
+            if (flags & CORRIF_NORM_RELU_IN) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s0[e] += (double)v[e]; s1[e] += (double)v[e] * (double)v[e]; }
+            } else {
+                f32x4 gv = *reinterpret_cast<const f32x4*>(dy + row * lddy + c4 * 4);
+                if (flags & CORRIF_NORM_RELU_OUT) {
+                    f32x4 yv = *reinterpret_cast<const f32x4*>(y + row * ldy + c4 * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gv[e] = yv[e] > 0.f ? gv[e] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float xh = (v[e] - mu[e]) * rs[e];
+                    s0[e] += (double)gv[e];
+                    s1[e] += (double)gv[e] * (double)xh;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[tid * 8 + e] = s0[e]; red[tid * 8 + 4 + e] = s1[e]; }
+    __syncthreads();
+    if (rl == 0 && c4 < n.C4) {
+        for (int k = 1; k < n.RL; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s0[e] += red[(k * n.CT + cl) * 8 + e]; s1[e] += red[(k * n.CT + cl) * 8 + 4 + e]; }
+        double* o = part + ((int64_t)(g * n.chunks + chunk) * C + c4 * 4) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e * 2] = s0[e]; o[e * 2 + 1] = s1[e]; }
+    }
+}
+
+__global__ void norm_stats_final_kernel(const double* __restrict__ part, int chunks, int G, int C, int64_t rows_per_group, float eps,
+                                        float* __restrict__ mean, float* __restrict__ rstd, float* running_mean,
+                                        float* running_var, float momentum) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * C) return;
+    int g = i / C, c = i - g * C;
+    double s = 0, q = 0;
+    for (int k = 0; k < chunks; ++k) {
+        const double* o = part + ((int64_t)(g * chunks + k) * C + c) * 2;
+        s += o[0];
+        q += o[1];
+    }
+    double m = s / (double)rows_per_group;
+    double var = q / (double)rows_per_group - m * m;
+    if (var < 0) var = 0;
+    mean[i] = (float)m;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {   // G == 1 ; momentum update with the unbiased variance (nn.BatchNorm3d training)
+        double unb = rows_per_group > 1 ? var * (double)rows_per_group / (double)(rows_per_group - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+    }
+}
+
+// sums[(g*C + c)*2 + {0,1}] = (sum g, sum g*xhat) ; optional dgamma/dbeta
+__global__ void norm_bwd_final_kernel(const double* __restrict__ part, int chunks, int G, int C, float* __restrict__ sums,
+                                      float* dgamma, float* dbeta) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * C) return;
+    int g = i / C, c = i - g * C;
+    double s = 0, q = 0;
+    for (int k = 0; k < chunks; ++k) {
+        const double* o = part + ((int64_t)(g * chunks + k) * C + c) * 2;
+        s += o[0];
+        q += o[1];
+    }
+    sums[i * 2] = (float)s;
+    sums[i * 2 + 1] = (float)q;
+    if (dgamma) dgamma[c] = (float)q;
+    if (dbeta) dbeta[c] = (float)s;
+}
+
+__global__ void eval_rstd_kernel(const float* __restrict__ var, float eps, float* __restrict__ rstd, int C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C) rstd[i] = 1.0f / sqrtf(var[i] + eps);
+}
+
+
+// element-wise passes: block = (row block, channel tile, group); thread (cl, rl) owns chunk c4 and rows rl, rl+RL, ...
+struct ApplyGeo { int CT, RL, C4; int64_t rows_per_block; };
+static ApplyGeo apply_geo(int64_t rows_per_group, int C, int& nblk, int& ctiles) {
+    ApplyGeo a;
+    a.C4 = C / 4;
+    a.CT = a.C4 < 256 ? a.C4 : 256;
+    a.RL = 256 / a.CT;
+    ctiles = (a.C4 + a.CT - 1) / a.CT;
+    int64_t per = (int64_t)a.RL * 8;
+    int64_t nb = (rows_per_group + per - 1) / per;
+    if (nb > 16384) nb = 16384;
+    if (nb < 1) nb = 1;
+    a.rows_per_block = (rows_per_group + nb - 1) / nb;
+    nblk = (int)((rows_per_group + a.rows_per_block - 1) / a.rows_per_block);
+    return a;
+}
+
+__global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ res, int64_t ldr,
+                                                         float* __restrict__ y, int64_t ldy, int64_t rows_per_group, int C, int flags,
+                                                         ApplyGeo a) {
+    const int tid = threadIdx.x, cl = tid % a.CT, rl = tid / a.CT;
+    const int c4 = blockIdx.y * a.CT + cl, g = blockIdx.z;
+    if (rl >= a.RL || c4 >= a.C4) return;
+    const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
+    int64_t r1 = r0 + a.rows_per_block;
+    if (r1 > rows_per_group) r1 = rows_per_group;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (int64_t)g * C + c4 * 4);
+    const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + (int64_t)g * C + c4 * 4);
+    f32x4 ga = {1, 1, 1, 1}, be = {0, 0, 0, 0};
+    if (gamma) ga = *reinterpret_cast<const f32x4*>(gamma + c4 * 4);
+    if (beta) be = *reinterpret_cast<const f32x4*>(beta + c4 * 4);
+    for (int64_t r = r0 + rl; r < r1; r += a.RL) {
+        const int64_t row = (int64_t)g * rows_per_group + r;
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ldx + c4 * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float xv = (flags & CORRIF_NORM_RELU_IN) ? fmaxf(v[e], 0.f) : v[e];
+            o[e] = (xv - mu[e]) * rs[e] * ga[e] + be[e];
+        }
+        if (res) {
+            f32x4 rv = *reinterpret_cast<const f32x4*>(res + row * ldr + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += rv[e];
+        }
+        if (flags & CORRIF_NORM_RELU_OUT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(y + row * ldy + c4 * 4) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ y,
+                                                             int64_t ldy, const float* __restrict__ x, int64_t ldx,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                             float* __restrict__ dx, int64_t lddx, float* __restrict__ dres,
+                                                             int64_t lddres, int64_t rows_per_group, int C, int flags, int frozen,
+                                                             ApplyGeo a) {
+    const int tid = threadIdx.x, cl = tid % a.CT, rl = tid / a.CT;
+    const int c4 = blockIdx.y * a.CT + cl, g = blockIdx.z;
+    if (rl >= a.RL || c4 >= a.C4) return;
+    const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
+    int64_t r1 = r0 + a.rows_per_block;
+    if (r1 > rows_per_group) r1 = rows_per_group;
+    const float invn = 1.0f / (float)rows_per_group;
+    f32x4 mu = {0, 0, 0, 0}, rs = {1, 1, 1, 1}, ga = {1, 1, 1, 1}, sg = {0, 0, 0, 0}, sgx = {0, 0, 0, 0};
+    if (dx) {
+        mu = *reinterpret_cast<const f32x4*>(mean + (int64_t)g * C + c4 * 4);
+        rs = *reinterpret_cast<const f32x4*>(rstd + (int64_t)g * C + c4 * 4);
+        if (gamma) ga = *reinterpret_cast<const f32x4*>(gamma + c4 * 4);
+        if (!frozen) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sg[e] = sums[((int64_t)g * C + c4 * 4 + e) * 2] * invn;
+                sgx[e] = sums[((int64_t)g * C + c4 * 4 + e) * 2 + 1] * invn;
+            }
+        }
+    }
+    for (int64_t r = r0 + rl; r < r1; r += a.RL) {
+        const int64_t row = (int64_t)g * rows_per_group + r;
+        f32x4 gv = *reinterpret_cast<const f32x4*>(dy + row * lddy + c4 * 4);
+        if (flags & CORRIF_NORM_RELU_OUT) {
+            f32x4 yv = *reinterpret_cast<const f32x4*>(y + row * ldy + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gv[e] = yv[e] > 0.f ? gv[e] : 0.f;
+        }
+        if (dres) *reinterpret_cast<f32x4*>(dres + row * lddres + c4 * 4) = gv;
+        if (dx) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ldx + c4 * 4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float xv = (flags & CORRIF_NORM_RELU_IN) ? fmaxf(v[e], 0.f) : v[e];
+                float t = gv[e];
+                if (!frozen) t = gv[e] - sg[e] - (xv - mu[e]) * rs[e] * sgx[e];
+                float d = ga[e] * rs[e] * t;
+                if ((flags & CORRIF_NORM_RELU_IN) && !(v[e] > 0.f)) d = 0.f;
+                o[e] = d;
+            }
+            *reinterpret_cast<f32x4*>(dx + row * lddx + c4 * 4) = o;
+        }
+    }
+}
+
+static bool norm_args_ok(int64_t rows_per_group, int G, int C) {
+    if (rows_per_group <= 0 || G <= 0 || G > 65535 || C <= 0 || (C & 3)) return false;
+    if (rows_per_group * G >= ((int64_t)1 << 31)) return false;
+    return true;
+}
+static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" int corrif_norm_stats(const float* x, int64_t ldx, int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, float eps,
+                                 float* mean, float* rstd, float* running_mean, float* running_var, float momentum, double* ws,
+                                 void* stream) {
+    if (!x || !mean || !rstd || !ws || !norm_args_ok(rows_per_group, G, C)) return CORRIF_EINVAL;
+    if ((ldx & 3) || !al16(x)) return CORRIF_EUNSUPPORTED;
+    if (running_mean && (G != 1 || !running_var)) return CORRIF_EINVAL;
+    NormGeo n = norm_geo(rows_per_group, G, C);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((norm_partial_kernel<0>), dim3(n.chunks, n.ctiles, G), dim3(256), 0, s, x, ldx, (const float*)nullptr, (int64_t)0,
+                       (const float*)nullptr, (int64_t)0, (const float*)nullptr, (const float*)nullptr, ws, rows_per_group, (int)C,
+                       (int)flags, n);
+    CORRIF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(norm_stats_final_kernel, dim3((G * C + 255) / 256), dim3(256), 0, s, (const double*)ws, n.chunks, (int)G, (int)C,
+                       rows_per_group, eps, mean, rstd, running_mean, running_var, momentum);
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}
+
+extern "C" int corrif_norm_eval_rstd(const float* running_var, float eps, float* rstd, int32_t C, void* stream) {
+    if (!running_var || !rstd || C <= 0) return CORRIF_EINVAL;
+    hipLaunchKernelGGL(eval_rstd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, running_var, eps, rstd, (int)C);
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}
+
+extern "C" int corrif_norm_apply(const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
+                                 const float* beta, const float* residual, int64_t ldr, float* y, int64_t ldy,
+                                 int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, void* stream) {
+    if (!x || !mean || !rstd || !y || !norm_args_ok(rows_per_group, G, C)) return CORRIF_EINVAL;
+    if ((ldx & 3) || (ldy & 3) || (ldr & 3) || !al16(x) || !al16(y) || !al16(residual) || !al16(mean) || !al16(rstd) ||
+        !al16(gamma) || !al16(beta))
+        return CORRIF_EUNSUPPORTED;
+    int nblk, ctiles;
+    ApplyGeo a = apply_geo(rows_per_group, C, nblk, ctiles);
+    hipLaunchKernelGGL(norm_apply_kernel, dim3(nblk, ctiles, G), dim3(256), 0, (hipStream_t)stream, x, ldx, mean, rstd, gamma, beta,
+                       residual, ldr, y, ldy, rows_per_group, (int)C, (int)flags, a);
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}
+
+extern "C" int corrif_norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                               const float* mean, const float* rstd, const float* gamma, float* dx, int64_t lddx, float* dres,
+                               int64_t lddres, float* dgamma, float* dbeta, int64_t rows_per_group, int32_t G, int32_t C,
+                               int32_t flags, int32_t frozen, double* ws, void* stream) {
+    if (!dy || !norm_args_ok(rows_per_group, G, C) || !ws) return CORRIF_EINVAL;
+    if ((flags & CORRIF_NORM_RELU_OUT) && !y) return CORRIF_EINVAL;
+    if (dx && (!x || !mean || !rstd)) return CORRIF_EINVAL;
+    if ((dgamma || dbeta) && (G != 1 || !x || !mean || !rstd)) return CORRIF_EINVAL;
+    if ((lddy & 3) || (ldy & 3) || (ldx & 3) || (lddx & 3) || (lddres & 3) || !al16(dy) || !al16(y) || !al16(x) || !al16(dx) ||
+        !al16(dres) || !al16(mean) || !al16(rstd) || !al16(gamma))
+        return CORRIF_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    NormGeo n = norm_geo(rows_per_group, G, C);
+    // sums live behind the double partials in the same workspace
+    float* sums = reinterpret_cast<float*>(ws + (size_t)G * n.chunks * C * 2);
+    const bool need_sums = (!frozen && dx) || dgamma || dbeta;
+    if (need_sums) {
+        hipLaunchKernelGGL((norm_partial_kernel<1>), dim3(n.chunks, n.ctiles, G), dim3(256), 0, s, x, ldx, dy, lddy, y, ldy, mean, rstd, ws,
+                           rows_per_group, (int)C, (int)flags, n);
+        CORRIF_CHECK_LAUNCH();
+        hipLaunchKernelGGL(norm_bwd_final_kernel, dim3((G * C + 255) / 256), dim3(256), 0, s, (const double*)ws, n.chunks, (int)G, (int)C,
+                           sums, dgamma, dbeta);
+        CORRIF_CHECK_LAUNCH();
+    }
+    if (dx || dres) {
+        int nblk, ctiles;
+        ApplyGeo a = apply_geo(rows_per_group, C, nblk, ctiles);
+        hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(nblk, ctiles, G), dim3(256), 0, s, dy, lddy, y, ldy, x, ldx, mean, rstd, gamma,
+                           (const float*)sums, dx, lddx, dres, lddres, rows_per_group, (int)C, (int)flags, (int)frozen, a);
+        CORRIF_CHECK_LAUNCH();
+    }
+    return CORRIF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over C (multiple of 256, <= 1024): one wave per row, C/64 values per lane in registers.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int NV>   // float4 per lane; C = NV*256
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pos, int64_t pos_rows,
+                                                            float* __restrict__ xsum, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, float eps) {
+    constexpr int C = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        v[k] = *reinterpret_cast<const f32x4*>(x + row * C + (k * 64 + lane) * 4);
+        if (pos) {
+            f32x4 pv = *reinterpret_cast<const f32x4*>(pos + (row % pos_rows) * C + (k * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[k][e] += pv[e];
+            if (xsum) *reinterpret_cast<f32x4*>(xsum + row * C + (k * 64 + lane) * 4) = v[k];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += v[k][e];
+    }
+    const float mu = wave_sum(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float d = v[k][e] - mu; q += d * d; }
+    const float rs = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + (k * 64 + lane) * 4);
+        f32x4 be = *reinterpret_cast<const f32x4*>(beta + (k * 64 + lane) * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[k][e] - mu) * rs * ga[e] + be[e];
+        *reinterpret_cast<f32x4*>(y + row * C + (k * 64 + lane) * 4) = o;
+    }
+}
+
+// dx per row + per-block partial (dgamma, dbeta) over a slab of rows
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, float* __restrict__ dx,
+                                                            double* __restrict__ part, int64_t rows, int rows_per_block) {
+    constexpr int C = NV * 256;
+    __shared__ float red[4][2][C];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    f32x4 ga[NV], ag[NV], ab[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        ga[k] = *reinterpret_cast<const f32x4*>(gamma + (k * 64 + lane) * 4);
+        ag[k] = (f32x4){0, 0, 0, 0};
+        ab[k] = (f32x4){0, 0, 0, 0};
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (int64_t row = r0 + w; row < r1; row += 4) {
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 g[NV], xh[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            g[k] = *reinterpret_cast<const f32x4*>(dy + row * C + (k * 64 + lane) * 4);
+            f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * C + (k * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[k][e] = (xv[e] - mu) * rs;
+                ag[k][e] += g[k][e] * xh[k][e];
+                ab[k][e] += g[k][e];
+                float gg = g[k][e] * ga[k][e];
+                s1 += gg;
+                s2 += gg * xh[k][e];
+            }
+        }
+        s1 = wave_sum(s1) * (1.0f / C);
+        s2 = wave_sum(s2) * (1.0f / C);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rs * (g[k][e] * ga[k][e] - s1 - xh[k][e] * s2);
+            *reinterpret_cast<f32x4*>(dx + row * C + (k * 64 + lane) * 4) = o;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[w][0][(k * 64 + lane) * 4 + e] = ag[k][e];
+            red[w][1][(k * 64 + lane) * 4 + e] = ab[k][e];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double a = 0, b = 0;
+        for (int ww = 0; ww < 4; ++ww) { a += red[ww][0][c]; b += red[ww][1][c]; }
+        part[((int64_t)blockIdx.x * C + c) * 2] = a;
+        part[((int64_t)blockIdx.x * C + c) * 2 + 1] = b;
+    }
+}
+__global__ void layernorm_bwd_final_kernel(const double* __restrict__ part, int nblk, int C, float* dgamma, float* dbeta) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0, b = 0;
+    for (int k = 0; k < nblk; ++k) { a += part[((int64_t)k * C + c) * 2]; b += part[((int64_t)k * C + c) * 2 + 1]; }
+    dgamma[c] = (float)a;
+    dbeta[c] = (float)b;
+}
+static int ln_blocks(int64_t rows, int& rpb) {
+    int64_t nb = (rows + 31) / 32;
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    rpb = (int)((rows + nb - 1) / nb);
+    return (int)((rows + rpb - 1) / rpb);
+}
+extern "C" size_t corrif_layernorm_workspace(int64_t rows, int32_t C) {
+    int rpb;
+    int nb = ln_blocks(rows, rpb);
+    return (size_t)nb * C * 2 * sizeof(double);
+}
+extern "C" int corrif_layernorm_fwd(const float* x, const float* pos, int64_t pos_rows, float* xsum, const float* gamma,
+                                    const float* beta, float* y, float* mean, float* rstd, int64_t rows, int32_t C, float eps,
+                                    void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0) return CORRIF_EINVAL;
+    if (pos && pos_rows <= 0) return CORRIF_EINVAL;
+    if (C != 512) return CORRIF_EUNSUPPORTED;
+    if (!al16(x) || !al16(pos) || !al16(xsum) || !al16(y) || !al16(gamma) || !al16(beta)) return CORRIF_EUNSUPPORTED;
+    hipLaunchKernelGGL((layernorm_fwd_kernel<2>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, pos, pos_rows, xsum,
+                       gamma, beta, y, mean, rstd, rows, eps);
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}
+extern "C" int corrif_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx,
+                                    double* ws, float* dgamma, float* dbeta, int64_t rows, int32_t C, void* stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || !ws || !dgamma || !dbeta || rows <= 0) return CORRIF_EINVAL;
+    if (C != 512) return CORRIF_EUNSUPPORTED;
+    if (!al16(dy) || !al16(x) || !al16(dx) || !al16(gamma)) return CORRIF_EUNSUPPORTED;
+    int rpb;
+    int nb = ln_blocks(rows, rpb);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((layernorm_bwd_kernel<2>), dim3(nb), dim3(256), 0, s, dy, x, mean, rstd, gamma, dx, ws, rows, rpb);
+    CORRIF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)ws, nb, (int)C, dgamma, dbeta);
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}

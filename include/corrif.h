@@ -1,0 +1,245 @@
+/* corrif.h - C-ABI of the MI355X (gfx950) kernels behind the CorrIFNet `MMVit4` hot path.
+ *
+ * The reference (a pure-Python PyTorch repository) has no FFI layer: its "operator API" for this
+ * path is the nn.Module protocol of `mmvit4.MMVit4` (mmvit4.py:391-532) whose forward/backward is
+ * executed by ATen ops.  Each entry point below replaces the ATen op(s) named in its comment, for
+ * the call sites cited (file:line in the upstream repository).  The reference-side binding a
+ * maintainer would add is the ctypes stub shown in INTEGRATION.md (the host mirror in this repo is
+ * `<package>/corrif_hip.py`).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless noted; fp32 data.
+ *  - activations are channels-last: a tensor [B, D, H, W, C] is a matrix of B*D*H*W rows; `ld*`
+ *    arguments are the row pitch in floats (>= channel count) so that channel slices of a wider
+ *    (concatenated) buffer can be read / written in place.
+ *  - the caller owns all memory (inputs, outputs, workspaces); kernels never allocate or free.
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); no implicit sync.
+ *  - return 0 on success, CORRIF_EINVAL (-1) bad argument, CORRIF_EUNSUPPORTED (-2),
+ *    CORRIF_ELAUNCH (-3) launch failure (hipGetLastError != hipSuccess).  No C++ exception
+ *    crosses this boundary.
+ */
+#ifndef CORRIF_H
+#define CORRIF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CORRIF_OK 0
+#define CORRIF_EINVAL (-1)
+#define CORRIF_EUNSUPPORTED (-2)
+#define CORRIF_ELAUNCH (-3)
+
+#define CORRIF_ABI_VERSION 1
+int corrif_abi_version(void);
+/* name of the gfx target the library was built for ("gfx950") - host-only call */
+const char* corrif_build_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Geometry of an implicit-GEMM gather: how GEMM row r = (n, rd, rh, rw) and filter tap
+ * t = (td, th, tw) address a source voxel.  For each axis
+ *      num = r*mul + dir*t + off ;  valid iff num % div == 0 ; s = num / div
+ * and then s must lie in [0, S) (zero padding) or is clamped into it (replicate padding).
+ *   forward conv   : mul = stride, dir = +1, off = -pad, div = 1
+ *   data gradient  : mul = 1,      dir = -1, off = +pad, div = stride   (transposed conv)
+ * is_gemm = 1 skips all of it: source row = GEMM row (1x1x1 stride-1 convs, nn.Linear, bmm).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct CorrifGeom {
+    int32_t is_gemm;
+    int32_t Rd, Rh, Rw;        /* per-sample grid the GEMM rows enumerate            */
+    int32_t Sd, Sh, Sw;        /* per-sample grid of the source tensor               */
+    int32_t kd, kh, kw;        /* filter taps                                        */
+    int32_t mul_d, mul_h, mul_w;
+    int32_t off_d, off_h, off_w;
+    int32_t div_d, div_h, div_w;
+    int32_t dir;               /* +1 / -1                                            */
+    int32_t clamp;             /* 0 zero padding, 1 replicate padding                */
+    int32_t ntaps;             /* valid taps (<= kd*kh*kw; K may be padded past it)  */
+    int64_t src_batch_pitch;   /* floats between samples of the source; 0 = dense    */
+} CorrifGeom;
+
+/* activation codes for epilogues */
+#define CORRIF_ACT_NONE 0
+#define CORRIF_ACT_RELU 1
+#define CORRIF_ACT_GELU 2      /* exact erf GELU (F.gelu default, mmvit4.py:341-345) */
+
+/* C[z][M,N] = act( gather(A)[M,K] * B^T + bias[N] + addend[M,N] )   K = taps*Cs
+ * Replaces aten::convolution forward for every nn.Conv3d with Cin % 4 == 0 on the path
+ * (mmvit4.py:32,72,131-135,161-168,398-426,237-264; Cs = 1: the stem, mmvit4.py:120), aten::convolution_backward's data gradient
+ * (geom.dir = -1), aten::addmm/mm of nn.Linear (mmvit4.py:301,303,351,354) and their input
+ * gradients, and aten::bmm (q@k^T, attn@v: mmvit4.py:309,312) through the z batch.
+ *   b_layout 0: B is [N][K] (K contiguous, pitch ldb)     1: B is [K][N] (N contiguous, pitch ldb)
+ *   z = zo*Zi + zi ; operand X is offset by zo*sX_o + zi*sX_i floats (X in A,B,C).
+ * FP32-input MFMA (v_mfma_f32_32x32x2_f32): results are exact-f32 fma chains. */
+typedef struct CorrifGemm {
+    const float* A; int64_t lda; int32_t Cs;     /* channels per tap (multiple of 4, or 1)  */
+    const float* B; int64_t ldb; int32_t b_layout;
+    float* C; int64_t ldc;
+    const float* bias;                            /* [N] or NULL                             */
+    const float* addend; int64_t ld_add;          /* [M][N] or NULL                          */
+    int32_t M, N, K; int32_t act;
+    int32_t Z, Zi;                                /* batch count (>=1), inner batch extent   */
+    int64_t sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
+    CorrifGeom g;
+} CorrifGemm;
+int corrif_gemm_fwd(const CorrifGemm* p, void* stream);
+
+/* W-type contraction over rows:  C[z][M,N] = sum_r A[r][M] * gather(B)[r][N]     N = taps*Cs
+ * Replaces aten::convolution_backward's weight gradient (A = dY, B = layer input) for every
+ * conv above, the weight gradients of nn.Linear, and the P^T*dO / dS^T*Q products of the
+ * attention backward (mmvit4.py:309,312).  R rows are split over `splits` workgroup groups that
+ * write fp32 slabs ws[split][M][N]; corrif_wgrad_reduce sums them deterministically. */
+typedef struct CorrifWgrad {
+    const float* A; int64_t lda;                  /* [R][M]                                  */
+    const float* B; int64_t ldb; int32_t Cs;      /* gathered source, channels per tap       */
+    float* C; int64_t ldc;                        /* [M][N] (used directly when splits == 1) */
+    float* ws;                                    /* splits*M*N floats when splits > 1       */
+    int32_t R, M, N; int32_t splits;
+    int32_t Z, Zi; int64_t sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;   /* batch (splits must be 1) */
+    CorrifGeom g;                                 /* rows = R enumerate g.R*, source = B     */
+} CorrifWgrad;
+int corrif_wgrad(const CorrifWgrad* p, void* stream);
+size_t corrif_wgrad_workspace(const CorrifWgrad* p);   /* bytes; host-only */
+int corrif_wgrad_plan(int32_t R, int32_t M, int32_t N);  /* recommended `splits`; host-only */
+
+/* out[i] = sum_j in[j*n + i], j < count (also used for bias gradients through col_sum) */
+int corrif_slab_reduce(const float* ws, float* out, int64_t n, int32_t count, void* stream);
+/* out[c] = sum_r x[r*ld + c]  (bias gradient; aten::sum in convolution_backward / addmm backward) */
+int corrif_col_sum(const float* x, int64_t ld, int64_t rows, int32_t C, float* out, double* ws, void* stream);
+size_t corrif_col_sum_workspace(int64_t rows, int32_t C);
+
+/* weight re-layouts (private caches of the host layer; reference layout is O,I,kd,kh,kw):
+ *   mode 0: out[o][t][i] = w[o][i][t]   (forward / weight-gradient layout, [N][K])
+ *   mode 1: out[t][o][i] = w[o][i][t]   (data-gradient layout, [K][N], taps NOT flipped: dir=-1)
+ *   mode 2: w[o][i][t] = in[o][t][i]    (weight-gradient back to the reference layout)          */
+int corrif_weight_repack(const float* in, float* out, int32_t O, int32_t I, int32_t T, int32_t mode, int64_t ldo, void* stream);
+/* ldo: row pitch (floats, >= T*I) of the [o][t][i] side in modes 0 and 2 (the stem pads 147 -> 148) */
+
+/* Stem: Conv3d(1->64,(3,7,7),stride (1,2,2),pad (1,3,3), no bias) on x[:, m] of the NCDHW input
+ * (mmvit4.py:120,172; aten::convolution with Cin = 1) runs through corrif_gemm_fwd / corrif_wgrad
+ * with Cs = 1 (scalar gather): lda = 1, g.src_batch_pitch = 3*D*H*W, K padded 147 -> 148 with
+ * g.ntaps = 147 and the packed weight [64][148] zero in its last column. */
+
+/* ------------------------------------------------------------------------------------------
+ * Normalisation over rows, channels-last.  groups G = 1 (BatchNorm3d: statistics over all rows,
+ * mmvit4.py:121,132-136,143) or G = B (InstanceNorm3d, affine=False: statistics per sample,
+ * mmvit4.py:24,34,74).  Replaces aten::native_batch_norm(+_backward) and the ReLU / residual add
+ * around it.   flags:
+ *   CORRIF_NORM_RELU_IN   x' = max(x,0) before the statistics       (conv->ReLU->IN, stem ReLU->BN)
+ *   CORRIF_NORM_RELU_OUT  y = max(y,0)                               (Bottleneck3D bn1/bn2/bn3)
+ *   CORRIF_NORM_EVAL      use mean/rstd as given (running statistics), no statistics pass
+ * ------------------------------------------------------------------------------------------ */
+#define CORRIF_NORM_RELU_IN 1
+#define CORRIF_NORM_RELU_OUT 2
+/* statistics: mean[G*C], rstd[G*C] (biased variance, eps); optional running-stat update (momentum,
+ * unbiased variance) when running_mean != NULL (G must be 1).  ws: corrif_norm_workspace bytes. */
+int corrif_norm_stats(const float* x, int64_t ldx, int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, float eps,
+                      float* mean, float* rstd, float* running_mean, float* running_var, float momentum,
+                      double* ws, void* stream);
+/* rstd[c] = 1/sqrt(var[c] + eps) for eval mode */
+int corrif_norm_eval_rstd(const float* running_var, float eps, float* rstd, int32_t C, void* stream);
+/* y = act_out( gamma*(x' - mean)*rstd + beta + residual ) ; gamma/beta/residual may be NULL */
+int corrif_norm_apply(const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                      const float* residual, int64_t ldr, float* y, int64_t ldy,
+                      int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, void* stream);
+/* backward.  g = dy * (y > 0) if RELU_OUT.  Produces
+ *   dx = [x>0 if RELU_IN] * gamma*rstd*( g - mean_g - xhat*mean_gxhat )      (train)
+ *   dx = [..] * gamma*rstd*g                                                (frozen = 1, eval statistics)
+ *   dres = g (optional), dgamma[c] = sum g*xhat, dbeta[c] = sum g (optional, G must be 1) */
+int corrif_norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                    const float* mean, const float* rstd, const float* gamma,
+                    float* dx, int64_t lddx, float* dres, int64_t lddres, float* dgamma, float* dbeta,
+                    int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, int32_t frozen, double* ws, void* stream);
+size_t corrif_norm_workspace(int64_t rows_per_group, int32_t G, int32_t C);
+
+/* LayerNorm over the last dim (C = 512), eps 1e-5 (mmvit4.py:327,335; aten::native_layer_norm).
+ * Optional fused pre-add: xin = x + pos[row % pos_rows] (Transformer.forward `x = x + pos`,
+ * mmvit4.py:385), written to xsum when non-NULL. */
+int corrif_layernorm_fwd(const float* x, const float* pos, int64_t pos_rows, float* xsum, const float* gamma, const float* beta,
+                         float* y, float* mean, float* rstd, int64_t rows, int32_t C, float eps, void* stream);
+int corrif_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                         float* dx, double* ws, float* dgamma, float* dbeta, int64_t rows, int32_t C, void* stream);
+size_t corrif_layernorm_workspace(int64_t rows, int32_t C);
+
+/* MaxPool3d((1,3,3),(1,2,2),(0,1,1)) channels-last (mmvit4.py:123,174; aten::max_pool3d_with_indices).
+ * idx: int8 window position (first maximum in (kh,kw) scan order, as ATen). */
+int corrif_maxpool133_fwd(const float* x, float* y, int8_t* idx, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C, void* stream);
+int corrif_maxpool133_bwd(const float* dy, const int8_t* idx, float* dx, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* F.interpolate(mode='trilinear', align_corners=True) / nn.Upsample (mmvit4.py:187-191,243,263;
+ * aten::upsample_trilinear3d[_backward]); channels-last, float index arithmetic as ATen.
+ * The backward is a deterministic gather (no atomics). */
+int corrif_trilinear_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t B, int32_t C,
+                         int32_t Di, int32_t Hi, int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, void* stream);
+int corrif_trilinear_bwd(const float* dy, int64_t lddy, float* dx, int64_t lddx, int32_t B, int32_t C,
+                         int32_t Di, int32_t Hi, int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, void* stream);
+/* F.interpolate(size) default mode 'nearest' (mmvit4.py:271,276,281,286; aten::upsample_nearest3d) */
+int corrif_nearest_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t B, int32_t C,
+                       int32_t Di, int32_t Hi, int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, void* stream);
+int corrif_nearest_bwd(const float* dy, int64_t lddy, float* dx, int64_t lddx, int32_t B, int32_t C,
+                       int32_t Di, int32_t Hi, int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, void* stream);
+/* adjoint of replicate padding (aten::replication_pad3d_backward, padding_mode='replicate' at
+ * mmvit4.py:225-235): dx[n,d,h,w] = sum of dxp over padded voxels that clamp to (d,h,w); dxp is
+ * the data gradient computed on the (D+2)(H+2)(W+2) padded grid. */
+int corrif_pad_fold(const float* dxp, float* dx, int64_t lddx, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* Row softmax with scale, in place: p = softmax(s*scale) (mmvit4.py:309-310; aten::_softmax),
+ * and its backward ds = scale * p * (dp - sum(dp*p)) (aten::_softmax_backward_data). */
+int corrif_softmax_rows(float* s, int64_t rows, int32_t n, float scale, void* stream);
+int corrif_softmax_rows_bwd(const float* p, float* dp_to_ds, int64_t rows, int32_t n, float scale, void* stream);
+
+/* Dropout with a counter-based Philox4x32-10 stream (replaces aten::bernoulli_/native_dropout at
+ * mmvit4.py:302,304,336,353,355): y = x * keep/(1-p), keep = u(seed, offset + i) >= p.
+ * The same call is its own backward (dx = dy * keep/(1-p)). x may alias y. */
+int corrif_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+
+/* element-wise helpers (aten::add / gelu_backward / mul): y = a + b ; dx = dy * gelu'(x) */
+int corrif_add(const float* a, const float* b, float* y, int64_t n, void* stream);
+int corrif_add_bcast_rows(const float* a, const float* b, int64_t b_n, float* y, int64_t n, void* stream); /* b index = i % b_n */
+int corrif_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+int corrif_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+/* strided 2-D copy / accumulate: dst[r*ldd + c] (+)= src[r*lds + c], c < C (torch.cat / chunk grads) */
+int corrif_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int32_t C, int32_t accumulate, void* stream);
+/* out[c] = sum over rows r of x[r*ld + c] for r in a group of `rows` (pos gradient: sum over batch) */
+int corrif_sum_groups(const float* x, float* out, int64_t group_elems, int32_t groups, void* stream);
+
+/* Inter-modal correlation, mmvit4.py:481-491 (+ the [3,B*C*S] -> [B,3C,S] re-view of :485).
+ * qkv[m]: channels-last [B*S, 3*C] rows (q | k | v column blocks) of modality m, S = 512, C = 512.
+ * out[m][b'][s][c] = sum_i' w * v_i'[b'][s][c],   w = softmax_i( q_m[b]*k_i[b] / sqrt(3) )[i]
+ * with (i, b) = divmod(3*b' + i', B) evaluated at the same (c, s)            
+ * out: 3 tensors [B*S, C] (pitch ldo).  Backward returns dqkv[m] in the same layout. */
+int corrif_intercorr_fwd(const float* qkv0, const float* qkv1, const float* qkv2, int64_t ldq,
+                         float* out0, float* out1, float* out2, int64_t ldo, int32_t B, int32_t S, int32_t C, void* stream);
+int corrif_intercorr_bwd(const float* qkv0, const float* qkv1, const float* qkv2, int64_t ldq,
+                         const float* do0, const float* do1, const float* do2, int64_t ldo,
+                         float* dqkv0, float* dqkv1, float* dqkv2, int32_t B, int32_t S, int32_t C, void* stream);
+
+/* Head: final_conv (Conv3d 8->3, 1x1x1, bias) + sigmoid, channels-last [rows,8] in, NCDHW
+ * [B,3,1,224,224] out (mmvit4.py:264,290-291).  Backward: d(logit) = dpred * p*(1-p), then
+ * dx[rows,8], and slabs for dw[3][8], db[3]. */
+int corrif_head_fwd(const float* x, const float* w, const float* b, float* pred, int32_t B, int32_t HW, void* stream);
+int corrif_head_bwd(const float* dpred, const float* pred, const float* x, const float* w,
+                    float* dx, float* dw, float* db, double* ws, int32_t B, int32_t HW, void* stream);
+size_t corrif_head_workspace(int32_t B, int32_t HW);
+
+/* Loss of the training step, F4_TRAIN.py:58-60: mean BCE-with-logits applied to the (already
+ * sigmoided) prediction; loss: 1 float; dpred = d loss / d pred (optional). */
+int corrif_bce_logits_mean(const float* pred, const float* target, int64_t n, float* loss, float* dpred, double* ws, void* stream);
+size_t corrif_bce_workspace(int64_t n);
+
+/* Jaccard2 / Jaccard / JaccardAndF1 of F5_JACCARD2.py:4-37 on y[n], y_pred[n]:
+ * out[0] = Jaccard2, out[1] = Jaccard (no complement branch), out[2] = F1 (JaccardAndF1).
+ * Partial sums are fp32 per lane-chunk (exact for 0/1 inputs) combined in a fixed order. */
+int corrif_jaccard(const float* y, const float* y_pred, int64_t n, float eps, float* out, float* ws, void* stream);
+size_t corrif_jaccard_workspace(int64_t n);
+
+/* Adam step, torch.optim.Adam defaults as F2_MAIN.py:168-169 (N1): p, m, v updated in place. */
+int corrif_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int32_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CORRIF_H */

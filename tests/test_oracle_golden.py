@@ -1,0 +1,88 @@
+"""CPU: the oracle restatement (oracle/mmvit4_oracle.py) against the fixtures captured from the upstream
+reference by tests/golden/make_golden.py.  Same torch ops in the same order => the fp32 comparison is tight."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import helpers
+from oracle import mmvit4_oracle as O
+
+META = json.load(open(os.path.join(helpers.GOLDEN, "meta.json")))
+CASES = {c["name"]: c for c in META["cases"]}
+
+
+def sample(t, n=64):
+    f = t.detach().reshape(-1)
+    n = min(n, f.numel())
+    idx = (torch.arange(n, dtype=torch.int64) * (f.numel() - 1)) // max(n - 1, 1)
+    return f[idx].double().numpy()
+
+
+def test_state_dict_inventory_matches_reference():
+    inv = json.load(open(os.path.join(helpers.GOLDEN, "state_dict_inventory.json")))
+    sd = O.MMVit4().state_dict()
+    assert list(sd.keys()) == list(inv.keys())            # same keys, same order (1140)
+    assert len(sd) == 1140
+    for k, v in sd.items():
+        assert list(v.shape) == inv[k][0], k
+        assert str(v.dtype).split(".")[-1] == inv[k][1], k
+    assert sum(p.numel() for p in O.MMVit4().parameters()) == META["n_params"] == 85479624
+
+
+def run_oracle(case, dtype):
+    torch.manual_seed(0)
+    model = O.MMVit4()
+    model.load_state_dict(helpers.make_state_dict(model.state_dict(), seed=case["wseed"], conv_gain=case["conv_gain"]))
+    model = model.to(dtype)
+    if case["mode"] == "eval":
+        model.eval()
+    else:
+        model.train()
+        O.set_dropout(model, False)
+    x, mask = helpers.make_inputs(case["B"], case["D"], case["H"], case["W"])
+    x, mask = x.to(dtype), mask.to(dtype)
+    pred = model(x)
+    return model, pred, mask
+
+
+# one fp32 case per mode keeps the CPU suite short; the others are exercised by make_golden's own asserts
+@pytest.mark.parametrize("name", ["tame_train_b2_d3_64", "tame_eval_b3_d3_64", "kaiming_train_b2_d3_96"])
+def test_oracle_matches_reference_fixture(name):
+    case = CASES[name]
+    g = np.load(os.path.join(helpers.GOLDEN, name + ".npz"))
+    model, pred, mask = run_oracle(case, torch.float32)
+    ps = pred.detach()[:, :, 0, ::4, ::4].double().numpy()
+    # identical ATen ops in identical order: allow only last-bit noise
+    np.testing.assert_allclose(ps, g["f32/pred_sample"], rtol=0, atol=2e-7)
+    assert abs(pred.detach().double().sum().item() - float(g["f32/pred_sum"])) < 1e-3
+    n = case["B"] * 224 * 224
+    j = helpers.jaccard2_ref(mask[:, 0].reshape(n, 1), pred.detach()[:, 0].reshape(n, 1)).double().numpy()
+    np.testing.assert_allclose(j, g["f32/jaccard2"], rtol=0, atol=1e-7)
+    if case["mode"] != "eval":
+        loss = O.train_step_loss(pred, mask)
+        loss.backward()
+        assert abs(loss.item() - float(g["f32/loss"])) < 1e-6
+        params = dict(model.named_parameters())
+        for k in helpers.GRAD_KEYS:
+            ref = g["f32/grad_sample/" + k]
+            got = sample(params[k].grad)
+            scale = max(np.abs(ref).max(), 1e-12)
+            assert np.abs(got - ref).max() <= 1e-4 * scale + 1e-9, k
+        nog = [k for k, p in params.items() if p.grad is None]
+        assert len(nog) == int(g["f32/nograd_count"]) == 18
+        assert all(k.startswith(helpers.NOGRAD_PREFIXES) for k in nog)
+        sd = model.state_dict()
+        for k in ("RGB_encoder.e1_bn.running_mean", "RGB_encoder.e1_bn.running_var"):
+            np.testing.assert_allclose(sample(sd[k]), g["f32/buf/" + k], rtol=1e-6, atol=1e-7)
+
+
+def test_fixture_self_consistency_fp32_vs_fp64():
+    """The reference's own fp32-vs-fp64 gap bounds what any fp32 implementation can be asked to match."""
+    g = np.load(os.path.join(helpers.GOLDEN, "tame_train_b2_d3_64.npz"))
+    gap = np.abs(g["f32/pred_sample"] - g["f64/pred_sample"]).max()
+    assert gap < 1e-3
+    assert abs(float(g["f32/jaccard2"][0]) - float(g["f64/jaccard2"][0])) < 1e-5
