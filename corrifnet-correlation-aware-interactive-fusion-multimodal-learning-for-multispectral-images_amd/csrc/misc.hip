@@ -38,6 +38,15 @@ extern "C" int corrif_add_bcast_rows(const float* a, const float* b, int64_t b_n
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
+__global__ void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    GRID_STRIDE(i, n) y[i] = gelu_erf(x[i]);
+}
+extern "C" int corrif_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {
+    if (!x || !y || n <= 0) return CORRIF_EINVAL;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}
 __global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, int64_t n) {
     GRID_STRIDE(i, n) dx[i] = dy[i] * gelu_erf_grad(x[i]);
 }
@@ -53,6 +62,16 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __res
 extern "C" int corrif_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
     if (!dy || !y || !dx || n <= 0) return CORRIF_EINVAL;
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n);
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}
+__global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ y, int64_t n) {
+    const float k = s[0];
+    GRID_STRIDE(i, n) y[i] = x[i] * k;
+}
+extern "C" int corrif_scale_dev(const float* x, const float* scalar, float* y, int64_t n, void* stream) {
+    if (!x || !scalar || !y || n <= 0) return CORRIF_EINVAL;
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, scalar, y, n);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }

@@ -1,0 +1,388 @@
+"""Drop-in `mmvit4.MMVit4` for MI355X: same nn.Module surface and state-dict as the reference
+(mmvit4.py:391-532), forward/backward executed by the gfx950 kernels of libcorrif_gfx950.so.
+
+    from mmvit4 import MMVit4          # as F2_MAIN.py:122-123 does
+    model = MMVit4().to("cuda")
+    pred = model(images)               # images [B,3,D,H,W] fp32 -> [B,3,1,224,224] in (0,1), autograd-connected
+
+Internals are channels-last (NDHWC): the reference's `permute(0,2,3,4,1).view(B,-1,512)` tokenisations
+(mmvit4.py:458-461, 499-501, 510-513) and the `[B,8,8,8,2048]` re-view (mmvit4.py:526) are free
+reinterpretations here, and every 1x1x1 convolution is a row-major GEMM.  Parameters keep the reference
+names, shapes and (O,I,kd,kh,kw) layout, so checkpoints are interchangeable in both directions.
+There is no CPU path: calling the model on CPU tensors raises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+import ops
+
+basic_dims = 8
+transformer_basic_dims = 512
+mlp_dim = 512
+num_heads = 8
+depth = 1
+num_modals = 3
+patch_size = 8
+_MODS = ("RGB", "NIR", "SWIR")
+
+
+def _triple(v):
+    return (v, v, v) if isinstance(v, int) else tuple(v)
+
+
+class Conv3dP(nn.Module):
+    """Parameter holder + launcher for one nn.Conv3d of the reference (weight O,I,kd,kh,kw; optional bias)."""
+
+    def __init__(self, cin, cout, k=1, stride=1, pad=0, bias=True, replicate=False):
+        super().__init__()
+        self.k, self.stride, self.pad, self.replicate = _triple(k), _triple(stride), _triple(pad), replicate
+        self.weight = nn.Parameter(torch.empty(cout, cin, *self.k))
+        fan_in = cin * self.k[0] * self.k[1] * self.k[2]
+        nn.init.kaiming_normal_(self.weight)                      # mmvit4.py:437-439
+        if bias:
+            self.bias = nn.Parameter(torch.empty(cout).uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in)))
+        else:
+            self.register_parameter("bias", None)
+
+    def forward(self, x, out=None):
+        return ops.conv3d(x, self.weight, self.bias, self.stride, self.pad, self.replicate, out)
+
+    def extra_repr(self):
+        return "%d, %d, kernel_size=%s, stride=%s, padding=%s%s%s" % (
+            self.weight.shape[1], self.weight.shape[0], self.k, self.stride, self.pad,
+            ", padding_mode=replicate" if self.replicate else "", "" if self.bias is not None else ", bias=False")
+
+
+class BatchNorm3dP(nn.Module):
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.eps, self.momentum = eps, momentum
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x, residual=None, relu_in=False, relu_out=False, out=None):
+        if self.training:
+            self.num_batches_tracked += 1
+        return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, residual, relu_in, relu_out,
+                              self.training, self.momentum, self.eps, out)
+
+    def extra_repr(self):
+        return "%d, eps=%g, momentum=%g" % (self.weight.numel(), self.eps, self.momentum)
+
+
+class InstanceNorm3dP(nn.Module):
+    """nn.InstanceNorm3d(affine=False, track_running_stats=False): no parameters, no buffers (mmvit4.py:24)."""
+
+    def forward(self, x, out=None):           # applied AFTER the ReLU, fused with it (mmvit4.py:41-45)
+        return ops.relu_instnorm(x, 1e-5, out)
+
+
+class general_conv3d_prenorm(nn.Module):
+    """conv(bias) -> ReLU -> InstanceNorm3d (mmvit4.py:29-45)."""
+
+    def __init__(self, in_ch, out_ch, k_size=3, stride=1, padding=1, pad_type="zeros"):
+        super().__init__()
+        self.conv = Conv3dP(in_ch, out_ch, k_size, stride, padding, True, pad_type == "replicate" and k_size != 1)
+        self.norm = InstanceNorm3dP()
+
+    def forward(self, x, out=None):
+        return self.norm(self.conv(x), out)
+
+
+class fusion_prenorm(nn.Module):
+    """RFM: 1x1x1, 3x3x3 (zero pad), 1x1x1 (mmvit4.py:47-56)."""
+
+    def __init__(self, in_channel=64, num_cls=1):
+        super().__init__()
+        self.fusion_layer = nn.Sequential(general_conv3d_prenorm(in_channel * num_cls, in_channel, 1, 1, 0),
+                                          general_conv3d_prenorm(in_channel, in_channel, 3, 1, 1),
+                                          general_conv3d_prenorm(in_channel, in_channel, 1, 1, 0))
+
+    def forward(self, x):
+        return self.fusion_layer(x)
+
+
+class EarlyFusionBlock(nn.Module):
+    """cat(3 modalities) -> 1x1x1 conv -> ReLU -> IN (mmvit4.py:64-81).  The concat buffer is filled in place
+    by the three encoders' adapt convolutions, so `forward` receives it already assembled."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        c = num_modals * in_channels
+        self.conv = Conv3dP(c, c, 1, 1, 0, True)
+        self.norm = InstanceNorm3dP()
+
+    def forward(self, cat):
+        return self.norm(self.conv(cat))
+
+
+class Bottleneck3D(nn.Module):
+    """mmvit4.py:196-212 with the inflated ResNet-50 convolutions of :126-151."""
+
+    def __init__(self, cin, width, stride, down):
+        super().__init__()
+        cout = 4 * width
+        self.conv1 = Conv3dP(cin, width, 1, 1, 0, False)
+        self.bn1 = BatchNorm3dP(width)
+        self.conv2 = Conv3dP(width, width, (1, 3, 3), (1, stride, stride), (0, 1, 1), False)
+        self.bn2 = BatchNorm3dP(width)
+        self.conv3 = Conv3dP(width, cout, 1, 1, 0, False)
+        self.bn3 = BatchNorm3dP(cout)
+        self.downsample = nn.Sequential(Conv3dP(cin, cout, 1, (1, stride, stride), 0, False), BatchNorm3dP(cout)) if down else None
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
+        y = self.bn1(self.conv1(x), relu_out=True)
+        y = self.bn2(self.conv2(y), relu_out=True)
+        return self.bn3(self.conv3(y), residual=idt, relu_out=True)
+
+
+def _res_layer(cin, width, n, stride):
+    return nn.Sequential(Bottleneck3D(cin, width, stride, True), *[Bottleneck3D(4 * width, width, 1, False) for _ in range(n - 1)])
+
+
+_ADAPT = ((64, basic_dims), (256, basic_dims * 2), (512, basic_dims * 4), (1024, basic_dims * 8), (2048, basic_dims * 8))
+
+
+class Encoder(nn.Module):
+    """mmvit4.py:113-194.  `forward` writes x1..x5 / x6 straight into channel slices of the early-fusion concat buffers."""
+
+    def __init__(self, inflate_time=3):
+        super().__init__()
+        self.e1_c1 = Conv3dP(1, 64, (inflate_time, 7, 7), (1, 2, 2), (inflate_time // 2, 3, 3), False)
+        self.e1_bn = BatchNorm3dP(64)
+        self.e2 = _res_layer(64, 64, 3, 1)
+        self.e3 = _res_layer(256, 128, 4, 2)
+        self.e4 = _res_layer(512, 256, 6, 2)
+        self.e5 = _res_layer(1024, 512, 3, 2)
+        self.conv6 = Conv3dP(basic_dims * 23, basic_dims * 8, 1)
+        for i, (ci, co) in enumerate(_ADAPT):
+            setattr(self, "adapt%d" % (i + 1), Conv3dP(ci, co, 1))
+
+    def forward(self, x, m, cats):
+        """x: [B, D, H, W] view of modality m; cats[l]: concat buffer of level l (None until the first modality allocates it)."""
+        f = ops.maxpool133(self.e1_bn(self.e1_c1(x), relu_in=True))          # conv -> ReLU -> BN -> pool (mmvit4.py:172-174)
+        feats = [f]
+        for layer in (self.e2, self.e3, self.e4, self.e5):
+            f = layer(f)
+            feats.append(f)
+        outs = []
+        B = x.shape[0]
+        cube = torch.empty((B, 8, 8, 8, basic_dims * 23), dtype=torch.float32, device=x.device)
+        parts, off = [], 0
+        for l, f in enumerate(feats):
+            c = _ADAPT[l][1]
+            if cats[l] is None:
+                cats[l] = torch.empty(f.shape[:4] + (num_modals * c,), dtype=torch.float32, device=x.device)
+            xl = getattr(self, "adapt%d" % (l + 1))(f, out=cats[l][..., m * c:(m + 1) * c])
+            outs.append(xl)
+            parts.append(ops.trilinear(xl, (8, 8, 8), out=cube[..., off:off + c]))     # mmvit4.py:187-191
+            off += c
+        if cats[5] is None:
+            cats[5] = torch.empty((B, 8, 8, 8, num_modals * basic_dims * 8), dtype=torch.float32, device=x.device)
+        c6 = basic_dims * 8
+        x6 = self.conv6(ops.cat_channels(cube, *parts), out=cats[5][..., m * c6:(m + 1) * c6])
+        return outs + [x6]
+
+
+class Decoder_fuse(nn.Module):
+    """mmvit4.py:222-292 (seg_* heads are parameter-bearing but unused, as in the reference)."""
+
+    def __init__(self, num_cls=1):
+        super().__init__()
+        b, rep = basic_dims, "replicate"
+        self.d4_c1 = general_conv3d_prenorm(b * 16, b * 16, pad_type=rep)
+        self.d4_c2 = general_conv3d_prenorm(320, b * 8, pad_type=rep)
+        self.d4_out = general_conv3d_prenorm(b * 8, b * 8, k_size=1, padding=0, pad_type=rep)
+        self.d3_c1 = general_conv3d_prenorm(b * 8, b * 4, pad_type=rep)
+        self.d3_c2 = general_conv3d_prenorm(128, b * 4, pad_type=rep)
+        self.d3_out = general_conv3d_prenorm(b * 4, b * 4, k_size=1, padding=0, pad_type=rep)
+        self.d2_c1 = general_conv3d_prenorm(b * 4, b * 2, pad_type=rep)
+        self.d2_c2 = general_conv3d_prenorm(64, b * 2, pad_type=rep)
+        self.d2_out = general_conv3d_prenorm(b * 2, b * 2, k_size=1, padding=0, pad_type=rep)
+        self.d1_c1 = general_conv3d_prenorm(b * 2, b, pad_type=rep)
+        self.d1_c2 = general_conv3d_prenorm(32, b, pad_type=rep)
+        self.d1_out = general_conv3d_prenorm(b, b, k_size=1, padding=0, pad_type=rep)
+        self.seg_d4 = Conv3dP(b * 8, num_cls, 1)
+        self.seg_d3 = Conv3dP(b * 8, num_cls, 1)
+        self.seg_d2 = Conv3dP(b * 4, num_cls, 1)
+        self.seg_d1 = Conv3dP(b * 2, num_cls, 1)
+        self.seg_layer = Conv3dP(b, num_cls, 1)
+        self.RFM5 = fusion_prenorm(b * 24)
+        self.RFM5_reduce = Conv3dP(b * 24, b * 16, 1)
+        self.RFM4 = fusion_prenorm(b * 24)
+        self.RFM3 = fusion_prenorm(b * 12)
+        self.RFM2 = fusion_prenorm(b * 6)
+        self.RFM1 = fusion_prenorm(b * 3)
+        self.final_conv = Conv3dP(8, 3, 1)
+
+    def forward(self, x1, x2, x3, x4, x5):
+        B, dev = x5.shape[0], x5.device
+        y = self.RFM5_reduce(self.RFM5(x5))
+        stages = ((self.RFM4, x4, 16, self.d4_c1, self.d4_c2, self.d4_out),
+                  (self.RFM3, x3, 32, self.d3_c1, self.d3_c2, self.d3_out),
+                  (self.RFM2, x2, 64, self.d2_c1, self.d2_c2, self.d2_out),
+                  (self.RFM1, x1, 128, self.d1_c1, self.d1_c2, self.d1_out))
+        for rfm, skip, n, c1, c2, cout in stages:
+            cs, cy = skip.shape[-1], c1.conv.weight.shape[0]
+            cat = torch.empty((B, n, n, n, cs + cy), dtype=torch.float32, device=dev)
+            up = ops.trilinear(y, (n, n, n))                                   # self.up2, align_corners (mmvit4.py:243)
+            part_y = c1(up, out=cat[..., cs:])                                 # d*_c1: 3x3x3 replicate -> ReLU -> IN
+            part_s = ops.nearest(rfm(skip), (n, n, n), out=cat[..., :cs])      # F.interpolate nearest (mmvit4.py:271-286)
+            y = cout(c2(ops.cat_channels(cat, part_s, part_y)))
+        up = ops.trilinear(y, (1, 224, 224))                                   # up_to_224 (mmvit4.py:263): depth slice 0 only
+        return ops.head(up, self.final_conv.weight, self.final_conv.bias)      # final_conv + sigmoid (mmvit4.py:290-291)
+
+
+class _Holder(nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+
+class LinearP(nn.Module):
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(cout).uniform_(-1.0 / math.sqrt(cin), 1.0 / math.sqrt(cin)))
+        else:
+            self.register_parameter("bias", None)
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+    def extra_repr(self):
+        return "in_features=%d, out_features=%d, bias=%s" % (self.weight.shape[1], self.weight.shape[0], self.bias is not None)
+
+
+class LayerNormP(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class SelfAttention(nn.Module):
+    """mmvit4.py:295-315"""
+
+    def __init__(self, dim, heads=8, dropout_rate=0.0):
+        super().__init__()
+        self.num_heads, self.p = heads, dropout_rate
+        self.qkv = LinearP(dim, dim * 3, bias=False)
+        self.proj = LinearP(dim, dim)
+
+    def forward(self, x):
+        o = ops.attention(self.qkv(x), self.num_heads, self.p, self.training)      # softmax(qk^T/sqrt(hd)) -> attn_drop -> @v
+        return ops.dropout(self.proj(o), self.p, self.training)                   # proj -> proj_drop
+
+
+class FeedForward(nn.Module):
+    """mmvit4.py:347-358: net.0 Linear, net.1 GELU, net.2 Dropout, net.3 Linear, net.4 Dropout"""
+
+    def __init__(self, dim, hidden, p):
+        super().__init__()
+        self.p = p
+        self.net = nn.ModuleList([LinearP(dim, hidden), nn.Identity(), nn.Identity(), LinearP(hidden, dim), nn.Identity()])
+
+    def forward(self, x):
+        h = ops.dropout(ops.gelu(self.net[0](x)), self.p, self.training)
+        return ops.dropout(self.net[3](h), self.p, self.training)
+
+
+class _PreNorm(nn.Module):
+    """PreNorm / PreNormDrop (mmvit4.py:324-339): parameters `norm.*`, `fn.*`"""
+
+    def __init__(self, dim, fn, p=None):
+        super().__init__()
+        self.norm = LayerNormP(dim)
+        self.fn = fn
+        self.p = p
+
+
+class Transformer(nn.Module):
+    """mmvit4.py:360-388 (depth blocks of Residual(PreNormDrop(attn)) + Residual(PreNorm(ffn)))."""
+
+    def __init__(self, embedding_dim, depth_, heads, mlp, dropout_rate=0.1, n_levels=1, n_points=4):
+        super().__init__()
+        self.depth = depth_
+        self.cross_attention_list = nn.ModuleList(
+            [_Holder(_PreNorm(embedding_dim, SelfAttention(embedding_dim, heads, dropout_rate), dropout_rate)) for _ in range(depth_)])
+        self.cross_ffn_list = nn.ModuleList(
+            [_Holder(_PreNorm(embedding_dim, FeedForward(embedding_dim, mlp, dropout_rate))) for _ in range(depth_)])
+
+    def forward(self, x, pos):
+        for j in range(self.depth):
+            att, ffn = self.cross_attention_list[j].fn, self.cross_ffn_list[j].fn
+            xs, h = ops.layer_norm(x, att.norm.weight, att.norm.bias, pos=pos)             # x = x + pos ; LN(x)
+            a = ops.dropout(att.fn(h), att.p, self.training)                                # PreNormDrop's dropout
+            x = ops.add(a, xs)                                                              # Residual
+            h = ops.layer_norm(x, ffn.norm.weight, ffn.norm.bias)
+            x = ops.add(ffn.fn(h), x)
+        return x
+
+
+class MMVit4(nn.Module):
+    def __init__(self, num_cls=1):
+        super().__init__()
+        d8, T = basic_dims * 8, transformer_basic_dims
+        self.RGB_encoder, self.NIR_encoder, self.SWIR_encoder = Encoder(), Encoder(), Encoder()
+        self.RGB_encode_conv, self.NIR_encode_conv, self.SWIR_encode_conv = Conv3dP(d8, T, 1), Conv3dP(d8, T, 1), Conv3dP(d8, T, 1)
+        self.fused6_encode_conv = Conv3dP(d8 * 3, T, 1)
+        self.RGB_decode_conv, self.NIR_decode_conv, self.SWIR_decode_conv = Conv3dP(T, d8, 1), Conv3dP(T, d8, 1), Conv3dP(T, d8, 1)
+        for m in _MODS + ("fused6",):
+            setattr(self, m + "_pos", nn.Parameter(torch.zeros(1, patch_size ** 3, T)))
+        self.RGB_transformer = Transformer(T, depth, num_heads, mlp_dim)
+        self.NIR_transformer = Transformer(T, depth, num_heads, mlp_dim)
+        self.SWIR_transformer = Transformer(T, depth, num_heads, mlp_dim)
+        self.qkv_RGB, self.qkv_NIR, self.qkv_SWIR = Conv3dP(T, T * 3, 1), Conv3dP(T, T * 3, 1), Conv3dP(T, T * 3, 1)
+        self.multimodal_transformer = Transformer(T, depth, num_heads, mlp_dim, n_levels=3)
+        self.multimodal_decode_conv = Conv3dP(T * 4, d8 * 3, 1)
+        self.decoder_fuse = Decoder_fuse(num_cls=num_cls)
+        for i, c in enumerate((basic_dims, basic_dims * 2, basic_dims * 4, d8, d8, d8)):
+            setattr(self, "fusion%d" % (i + 1), EarlyFusionBlock(c))
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("MMVit4 (MI355X build) runs on the GPU only: there is no CPU fall-back path")
+        if x.dtype != torch.float32 or x.dim() != 5 or x.shape[1] != num_modals:
+            raise ValueError("expected fp32 input [B, 3, D, H, W]")
+        B = x.shape[0]
+        P3, T = patch_size, transformer_basic_dims
+        cats = [None] * 6
+        feats = [getattr(self, m + "_encoder")(x[:, i], i, cats) for i, m in enumerate(_MODS)]
+        fused = [getattr(self, "fusion%d" % (l + 1))(ops.cat_channels(cats[l], *[feats[i][l] for i in range(num_modals)]))
+                 for l in range(6)]            # fused[4] (fusion5) is computed and never consumed, as in the reference (:453)
+
+        skip, trans = [], []
+        for i, m in enumerate(_MODS):
+            tok = getattr(self, m + "_encode_conv")(feats[i][5]).view(B, P3 ** 3, T)       # channels-last == token layout (:458-461)
+            skip.append(tok)
+            trans.append(getattr(self, m + "_transformer")(tok, getattr(self, m + "_pos")))
+        qkv = [getattr(self, "qkv_" + m)(trans[i].view(B, P3, P3, P3, T)).view(B, P3 ** 3, 3 * T) for i, m in enumerate(_MODS)]
+        corr = ops.inter_corr(qkv[0], qkv[1], qkv[2])                                      # mmvit4.py:481-503
+        mm = [ops.add(skip[i], corr[i]) for i in range(num_modals)]
+        mm.append(self.fused6_encode_conv(fused[5]).view(B, P3 ** 3, T))
+        pos = ops.cat_tokens(self.RGB_pos, self.NIR_pos, self.SWIR_pos, self.fused6_pos)
+        y = self.multimodal_transformer(ops.cat_tokens(*mm), pos)                          # [B, 2048, 512]
+        x6 = self.multimodal_decode_conv(y.view(B, P3, P3, P3, 4 * T))                     # 4 tokens -> one voxel (mmvit4.py:526)
+        return self.decoder_fuse(fused[0], fused[1], fused[2], fused[3], x6)
+
+
+def Jaccard2(y, y_pred, epsilon=1e-8):
+    """F5_JACCARD2.py:11-20 on the device; returns a [1] tensor like the reference."""
+    return ops.jaccard_all(y, y_pred, epsilon)[0:1]
+
+
+def Jaccard(y, y_pred, epsilon=1e-8):
+    return ops.jaccard_all(y, y_pred, epsilon)[1:2]
+
+
+def JaccardAndF1(y, y_pred, epsilon=1e-8):
+    return ops.jaccard_all(y, y_pred, epsilon)[2:3]

@@ -1,0 +1,753 @@
+"""autograd.Function wrappers over the C-ABI kernels (corrif_hip.py).
+
+Every forward/backward below enqueues hand-written gfx950 kernels only; torch supplies memory,
+views and the autograd graph.  Activations are channels-last: [B, D, H, W, C] (or [B, N, C] tokens),
+possibly as a channel-slice view of a wider concat buffer (row pitch `ld` > C).
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+import corrif_hip as H
+from corrif_hip import P, check, lib, stream
+
+NORM_RELU_IN, NORM_RELU_OUT = 1, 2
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+# --------------------------------------------------------------------------------------- helpers
+def rows_view(t):
+    """Return (t', rows, ld): last dim contiguous, every leading dim dense over a uniform row pitch `ld`,
+    16-byte aligned.  Copies (t.contiguous()) only when the layout cannot be described that way."""
+    C = t.shape[-1]
+    ok = t.stride(-1) == 1 or C == 1
+    ld = None
+    if ok:
+        expect = None
+        for i in range(t.dim() - 2, -1, -1):
+            if t.shape[i] == 1:
+                continue
+            if expect is None:
+                ld = t.stride(i)
+                expect = ld * t.shape[i]
+            else:
+                if t.stride(i) != expect:
+                    ok = False
+                    break
+                expect *= t.shape[i]
+        if ld is None:
+            ld = C
+        if ld < C or (ld & 3) or (t.data_ptr() & 15):
+            ok = False
+    if not ok:
+        t = t.contiguous()
+        ld = C
+    return t, t.numel() // C, ld
+
+
+def empty_like_rows(shape, ref):
+    return torch.empty(shape, dtype=torch.float32, device=ref.device)
+
+
+def _ws(nbytes, dev):
+    return H.ws_bytes(nbytes, dev)
+
+
+def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, addend=None, ld_add=0, act=ACT_NONE,
+         Z=1, Zi=1, sA=(0, 0), sB=(0, 0), sC=(0, 0)):
+    g = H.Gemm()
+    g.A, g.lda, g.Cs = A, lda, Cs
+    g.B, g.ldb, g.b_layout = Bm, ldb, b_layout
+    g.C, g.ldc = Cout, ldc
+    g.bias = bias if bias is not None else None
+    g.addend = addend if addend is not None else None
+    g.ld_add = ld_add
+    g.M, g.N, g.K, g.act = M, N, K, act
+    g.Z, g.Zi = Z, Zi
+    g.sA_o, g.sA_i = sA
+    g.sB_o, g.sB_i = sB
+    g.sC_o, g.sC_i = sC
+    g.g = geom
+    check(lib().corrif_gemm_fwd(g, stream()), "corrif_gemm_fwd")
+
+
+def wgrad(A, lda, Bm, ldb, Cs, Cout, ldc, R, M, N, geom, dev, Z=1, Zi=1, sA=(0, 0), sB=(0, 0), sC=(0, 0)):
+    w = H.Wgrad()
+    w.A, w.lda = A, lda
+    w.B, w.ldb, w.Cs = Bm, ldb, Cs
+    w.C, w.ldc = Cout, ldc
+    w.R, w.M, w.N = R, M, N
+    w.Z, w.Zi = Z, Zi
+    w.sA_o, w.sA_i = sA
+    w.sB_o, w.sB_i = sB
+    w.sC_o, w.sC_i = sC
+    w.g = geom
+    w.splits = 1 if Z > 1 else lib().corrif_wgrad_plan(R, M, N)
+    buf = None
+    if w.splits > 1:
+        buf = _ws(lib().corrif_wgrad_workspace(w), dev)
+        w.ws = buf.data_ptr()
+    check(lib().corrif_wgrad(w, stream()), "corrif_wgrad")
+
+
+def col_sum(t, rows, ld, C):
+    out = torch.empty(C, dtype=torch.float32, device=t.device)
+    ws = _ws(lib().corrif_col_sum_workspace(rows, C), t.device)
+    check(lib().corrif_col_sum(P(t), ld, rows, C, P(out), P(ws), stream()), "corrif_col_sum")
+    return out
+
+
+def repack(src, shape_out, O, I, T, mode, ldo, zero=False):
+    out = (torch.zeros if zero else torch.empty)(shape_out, dtype=torch.float32, device=src.device)
+    check(lib().corrif_weight_repack(P(src), P(out), O, I, T, mode, ldo, stream()), "corrif_weight_repack")
+    return out
+
+
+def _out_size(i, k, s, p):
+    return (i + 2 * p - k) // s + 1
+
+
+# --------------------------------------------------------------------------------------- convolution
+class ConvFn(Function):
+    """nn.Conv3d on channels-last activations.  weight stays in the reference (O,I,kd,kh,kw) layout."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, replicate, out, act):
+        Co, Ci, kd, kh, kw = weight.shape
+        T = kd * kh * kw
+        stem = Ci == 1
+        if stem:                                  # x: [B, D, H, W] strided view of the NCDHW input, one modality
+            B, Di, Hi, Wi = x.shape
+            if x.stride(3) != 1 or x.stride(2) != Wi or x.stride(1) != Hi * Wi:
+                x = x.contiguous()
+            lda, batch_pitch = 1, x.stride(0)
+        else:
+            x, _, lda = rows_view(x)
+            B, Di, Hi, Wi, _ = x.shape
+            batch_pitch = 0
+        Do, Ho, Wo = (_out_size(Di, kd, stride[0], pad[0]), _out_size(Hi, kh, stride[1], pad[1]), _out_size(Wi, kw, stride[2], pad[2]))
+        M = B * Do * Ho * Wo
+        if out is None:
+            out = torch.empty((B, Do, Ho, Wo, Co), dtype=torch.float32, device=x.device)
+        y, _, ldc = rows_view(out)
+        assert y is out, "conv output slice must be row-addressable"
+        is_gemm = T == 1 and stride == (1, 1, 1) and not stem
+        if stem:
+            Kp = (T + 3) // 4 * 4
+            wp = repack(weight, (Co, Kp), Co, 1, T, 0, Kp, zero=True)
+            geom = H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad, ntaps=T, src_batch_pitch=batch_pitch)
+            gemm(P(x), 1, P(wp), Kp, 0, P(y), ldc, M, Co, Kp, 1, geom, bias=P(bias) if bias is not None else None, act=act)
+        else:
+            wp = weight if T == 1 else repack(weight, (Co, T * Ci), Co, Ci, T, 0, T * Ci)
+            geom = H.gemm_geom() if is_gemm else H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad, clamp=replicate)
+            gemm(P(x), lda, P(wp), T * Ci, 0, P(y), ldc, M, Co, T * Ci, Ci, geom, bias=P(bias) if bias is not None else None, act=act)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad, replicate, bias is not None, (B, Di, Hi, Wi), (Do, Ho, Wo), stem, is_gemm, lda, batch_pitch)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        stride, pad, replicate, has_bias, (B, Di, Hi, Wi), (Do, Ho, Wo), stem, is_gemm, lda, batch_pitch = ctx.cfg
+        Co, Ci, kd, kh, kw = weight.shape
+        T = kd * kh * kw
+        gy, M, ldg = rows_view(gy)
+        dev = gy.device
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0] and not stem:
+            gx = torch.empty((B, Di, Hi, Wi, Ci), dtype=torch.float32, device=dev)
+            Min = B * Di * Hi * Wi
+            if is_gemm:        # dX[M,Ci] = dY[M,Co] . W[Co,Ci]   (W is the [K][N] operand as stored)
+                gemm(P(gy), ldg, P(weight), Ci, 1, P(gx), Ci, Min, Ci, Co, Co, H.gemm_geom())
+            else:
+                wd = weight if T == 1 else repack(weight, (T * Co, Ci), Co, Ci, T, 1, T * Ci)
+                if replicate:  # gradient on the replicate-padded grid, then fold the halo back (adjoint of the clamp)
+                    assert stride == (1, 1, 1) and pad == (1, 1, 1)
+                    Rg = (Di + 2, Hi + 2, Wi + 2)
+                    gxp = torch.empty((B,) + Rg + (Ci,), dtype=torch.float32, device=dev)
+                    geom = H.conv_geom(Rg, (Do, Ho, Wo), (kd, kh, kw), (1, 1, 1), (0, 0, 0), transposed=True)
+                    gemm(P(gy), ldg, P(wd), Ci, 1, P(gxp), Ci, B * Rg[0] * Rg[1] * Rg[2], Ci, T * Co, Co, geom)
+                    check(lib().corrif_pad_fold(P(gxp), P(gx), Ci, B, Di, Hi, Wi, Ci, stream()), "corrif_pad_fold")
+                else:
+                    geom = H.conv_geom((Di, Hi, Wi), (Do, Ho, Wo), (kd, kh, kw), stride, pad, transposed=True)
+                    gemm(P(gy), ldg, P(wd), Ci, 1, P(gx), Ci, Min, Ci, T * Co, Co, geom)
+        if ctx.needs_input_grad[1]:
+            if stem:
+                Kp = (T + 3) // 4 * 4
+                gwp = torch.empty((Co, Kp), dtype=torch.float32, device=dev)
+                geom = H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad, ntaps=T, src_batch_pitch=batch_pitch)
+                wgrad(P(gy), ldg, P(x), 1, 1, P(gwp), Kp, M, Co, Kp, geom, dev)
+                gw = repack(gwp, weight.shape, Co, 1, T, 2, Kp)
+            elif T == 1:
+                gw = torch.empty(weight.shape, dtype=torch.float32, device=dev)
+                geom = H.gemm_geom() if is_gemm else H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (1, 1, 1), stride, pad)
+                wgrad(P(gy), ldg, P(x), lda, Ci, P(gw), Ci, M, Co, Ci, geom, dev)
+            else:
+                gwp = torch.empty((Co, T * Ci), dtype=torch.float32, device=dev)
+                geom = H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad, clamp=replicate)
+                wgrad(P(gy), ldg, P(x), lda, Ci, P(gwp), T * Ci, M, Co, T * Ci, geom, dev)
+                gw = repack(gwp, weight.shape, Co, Ci, T, 2, T * Ci)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = col_sum(gy, M, ldg, Co)
+        return gx, gw, gb, None, None, None, None, None
+
+
+def conv3d(x, weight, bias=None, stride=(1, 1, 1), pad=(0, 0, 0), replicate=False, out=None, act=ACT_NONE):
+    return ConvFn.apply(x, weight, bias, tuple(stride), tuple(pad), bool(replicate), out, act)
+
+
+# --------------------------------------------------------------------------------------- linear
+class LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, M, lda = rows_view(x)
+        N, K = weight.shape
+        y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+        gemm(P(x), lda, P(weight), K, 0, P(y), N, M, N, K, K, H.gemm_geom(), bias=P(bias) if bias is not None else None)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        ctx.lda = lda
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        N, K = weight.shape
+        gy, M, ldg = rows_view(gy)
+        dev = gy.device
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(x.shape, dtype=torch.float32, device=dev)
+            gemm(P(gy), ldg, P(weight), K, 1, P(gx), K, M, K, N, N, H.gemm_geom())
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty(weight.shape, dtype=torch.float32, device=dev)
+            wgrad(P(gy), ldg, P(x), ctx.lda, K, P(gw), K, M, N, K, H.gemm_geom(), dev)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = col_sum(gy, M, ldg, N)
+        return gx, gw, gb
+
+
+linear = LinearFn.apply
+
+
+# --------------------------------------------------------------------------------------- BatchNorm / InstanceNorm
+def _norm_ws(rows_per_group, G, C, dev):
+    return _ws(lib().corrif_norm_workspace(rows_per_group, G, C), dev)
+
+
+class BatchNormFn(Function):
+    """y = act_out(gamma * (x' - mean) * rstd + beta + residual), x' = relu(x) if relu_in.  Statistics over all rows."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, flags, training, momentum, eps, out):
+        x, rows, ldx = rows_view(x)
+        C = x.shape[-1]
+        dev = x.device
+        if training:
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            rstd = torch.empty(C, dtype=torch.float32, device=dev)
+            ws = _norm_ws(rows, 1, C, dev)
+            check(lib().corrif_norm_stats(P(x), ldx, rows, 1, C, flags, eps, P(mean), P(rstd), P(running_mean), P(running_var),
+                                          momentum, P(ws), stream()), "corrif_norm_stats")
+        else:
+            mean = running_mean
+            rstd = torch.empty(C, dtype=torch.float32, device=dev)
+            check(lib().corrif_norm_eval_rstd(P(running_var), eps, P(rstd), C, stream()), "corrif_norm_eval_rstd")
+        ldr = 0
+        if residual is not None:
+            residual, _, ldr = rows_view(residual)
+        if out is None:
+            out = torch.empty(x.shape, dtype=torch.float32, device=dev)
+        y, _, ldy = rows_view(out)
+        assert y is out
+        check(lib().corrif_norm_apply(P(x), ldx, P(mean), P(rstd), P(gamma), P(beta), P(residual), ldr, P(y), ldy, rows, 1, C, flags,
+                                      stream()), "corrif_norm_apply")
+        ctx.save_for_backward(x, mean, rstd, gamma, y if (flags & NORM_RELU_OUT) else None)
+        ctx.cfg = (flags, not training, residual is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, mean, rstd, gamma, y = ctx.saved_tensors
+        flags, frozen, has_res = ctx.cfg
+        x, rows, ldx = rows_view(x)
+        gy, _, ldg = rows_view(gy)
+        C = x.shape[-1]
+        dev = x.device
+        ldy = 0
+        if y is not None:
+            y, _, ldy = rows_view(y)
+        gx = torch.empty(x.shape, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        gres = torch.empty(x.shape, dtype=torch.float32, device=dev) if (has_res and ctx.needs_input_grad[5]) else None
+        ggamma = torch.empty(C, dtype=torch.float32, device=dev)
+        gbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        ws = _norm_ws(rows, 1, C, dev)
+        check(lib().corrif_norm_bwd(P(gy), ldg, P(y), ldy, P(x), ldx, P(mean), P(rstd), P(gamma), P(gx), C, P(gres), C,
+                                    P(ggamma), P(gbeta), rows, 1, C, flags, 1 if frozen else 0, P(ws), stream()), "corrif_norm_bwd")
+        return gx, ggamma, gbeta, None, None, gres, None, None, None, None, None
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, residual=None, relu_in=False, relu_out=False, training=True,
+               momentum=0.1, eps=1e-5, out=None):
+    flags = (NORM_RELU_IN if relu_in else 0) | (NORM_RELU_OUT if relu_out else 0)
+    return BatchNormFn.apply(x, gamma, beta, running_mean, running_var, residual, flags, training, momentum, eps, out)
+
+
+class ReluInstNormFn(Function):
+    """InstanceNorm3d(relu(x)), affine=False, eps 1e-5: statistics per (sample, channel)."""
+
+    @staticmethod
+    def forward(ctx, x, eps, out):
+        x, rows, ldx = rows_view(x)
+        B, C = x.shape[0], x.shape[-1]
+        rpg = rows // B
+        dev = x.device
+        mean = torch.empty(B * C, dtype=torch.float32, device=dev)
+        rstd = torch.empty(B * C, dtype=torch.float32, device=dev)
+        ws = _norm_ws(rpg, B, C, dev)
+        check(lib().corrif_norm_stats(P(x), ldx, rpg, B, C, NORM_RELU_IN, eps, P(mean), P(rstd), None, None, 0.0, P(ws), stream()),
+              "corrif_norm_stats")
+        if out is None:
+            out = torch.empty(x.shape, dtype=torch.float32, device=dev)
+        y, _, ldy = rows_view(out)
+        assert y is out
+        check(lib().corrif_norm_apply(P(x), ldx, P(mean), P(rstd), None, None, None, 0, P(y), ldy, rpg, B, C, NORM_RELU_IN, stream()),
+              "corrif_norm_apply")
+        ctx.save_for_backward(x, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, mean, rstd = ctx.saved_tensors
+        x, rows, ldx = rows_view(x)
+        gy, _, ldg = rows_view(gy)
+        B, C = x.shape[0], x.shape[-1]
+        rpg = rows // B
+        dev = x.device
+        gx = torch.empty(x.shape, dtype=torch.float32, device=dev)
+        ws = _norm_ws(rpg, B, C, dev)
+        check(lib().corrif_norm_bwd(P(gy), ldg, None, 0, P(x), ldx, P(mean), P(rstd), None, P(gx), C, None, 0, None, None,
+                                    rpg, B, C, NORM_RELU_IN, 0, P(ws), stream()), "corrif_norm_bwd")
+        return gx, None, None
+
+
+def relu_instnorm(x, eps=1e-5, out=None):
+    return ReluInstNormFn.apply(x, eps, out)
+
+
+# --------------------------------------------------------------------------------------- LayerNorm
+class LayerNormFn(Function):
+    """pos given: returns (xs, y) = (x + pos, LN(x + pos))   (Transformer.forward `x = x + pos`, mmvit4.py:385)
+    pos None : returns y = LN(x)."""
+
+    @staticmethod
+    def forward(ctx, x, pos, gamma, beta, eps):
+        x = x.contiguous()
+        C = x.shape[-1]
+        rows = x.numel() // C
+        dev = x.device
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=dev)
+        rstd = torch.empty(rows, dtype=torch.float32, device=dev)
+        xs, pos_rows = x, 0
+        if pos is not None:
+            pos = pos.contiguous()
+            xs = torch.empty_like(x)
+            pos_rows = pos.numel() // C
+        check(lib().corrif_layernorm_fwd(P(x), P(pos), pos_rows, P(xs) if pos is not None else 0, P(gamma), P(beta), P(y), P(mean),
+                                         P(rstd), rows, C, eps, stream()), "corrif_layernorm_fwd")
+        ctx.save_for_backward(xs, mean, rstd, gamma)
+        ctx.pos_shape = None if pos is None else (pos.shape, pos_rows)
+        return (xs, y) if pos is not None else y
+
+    @staticmethod
+    def backward(ctx, *grads):
+        xs, mean, rstd, gamma = ctx.saved_tensors
+        gxs, gy = grads if ctx.pos_shape is not None else (None, grads[0])
+        C = xs.shape[-1]
+        rows = xs.numel() // C
+        dev = xs.device
+        gy = gy.contiguous()
+        gx = torch.empty_like(xs)
+        ggamma = torch.empty(C, dtype=torch.float32, device=dev)
+        gbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        ws = _ws(lib().corrif_layernorm_workspace(rows, C), dev)
+        check(lib().corrif_layernorm_bwd(P(gy), P(xs), P(mean), P(rstd), P(gamma), P(gx), P(ws), P(ggamma), P(gbeta), rows, C, stream()),
+              "corrif_layernorm_bwd")
+        gpos = None
+        if ctx.pos_shape is not None:
+            if gxs is not None:
+                gxs = gxs.contiguous()
+                check(lib().corrif_add(P(gx), P(gxs), P(gx), gx.numel(), stream()), "corrif_add")
+            shape, pos_rows = ctx.pos_shape
+            gpos = torch.empty(shape, dtype=torch.float32, device=dev)
+            check(lib().corrif_sum_groups(P(gx), P(gpos), pos_rows * C, rows // pos_rows, stream()), "corrif_sum_groups")
+        return gx, gpos, ggamma, gbeta, None
+
+
+def layer_norm(x, gamma, beta, pos=None, eps=1e-5):
+    """pos given: (x + pos, LN(x + pos)); else LN(x)"""
+    return LayerNormFn.apply(x, pos, gamma, beta, eps)
+
+
+# --------------------------------------------------------------------------------------- element-wise
+class AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        y = torch.empty_like(a)
+        check(lib().corrif_add(P(a), P(b), P(y), a.numel(), stream()), "corrif_add")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+add = AddFn.apply
+
+
+class GeluFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(lib().corrif_gelu_fwd(P(x), P(y), x.numel(), stream()), "corrif_gelu_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        check(lib().corrif_gelu_bwd(P(g), P(x), P(gx), x.numel(), stream()), "corrif_gelu_bwd")
+        return gx
+
+
+gelu = GeluFn.apply
+
+
+class _Philox:
+    """Counter-based dropout stream: (seed, running offset).  Re-seeded from torch's default generator on demand."""
+    seed = 0x5EED
+    offset = 0
+
+    @classmethod
+    def reserve(cls, n):
+        off = cls.offset
+        cls.offset += (n + 3) // 4 * 4
+        return cls.seed, off
+
+
+def manual_seed(seed):
+    _Philox.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    _Philox.offset = 0
+
+
+class DropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        x = x.contiguous()
+        seed, off = _Philox.reserve(x.numel())
+        y = torch.empty_like(x)
+        check(lib().corrif_dropout(P(x), P(y), x.numel(), p, seed, off, stream()), "corrif_dropout")
+        ctx.cfg = (p, seed, off)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        p, seed, off = ctx.cfg
+        g = g.contiguous()
+        gx = torch.empty_like(g)
+        check(lib().corrif_dropout(P(g), P(gx), g.numel(), p, seed, off, stream()), "corrif_dropout")
+        return gx, None
+
+
+def dropout(x, p, training):
+    if not training or p == 0.0:
+        return x
+    return DropoutFn.apply(x, p)
+
+
+# --------------------------------------------------------------------------------------- attention core
+class AttentionFn(Function):
+    """softmax(q k^T * scale) (dropout) v for qkv [B, N, 3*heads*hd] laid out as reshape(B,N,3,heads,hd) (mmvit4.py:307-312).
+    Scores are materialised ([B, heads, N, N]); q.k^T, p.v and the four backward products run on the MFMA GEMM kernels."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, p_drop, training):
+        qkv = qkv.contiguous()
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        hd = C // heads
+        dev = qkv.device
+        scale = hd ** -0.5
+        Z = B * heads
+        S = torch.empty((B, heads, N, N), dtype=torch.float32, device=dev)
+        base = qkv.data_ptr()
+        q_ptr, k_ptr, v_ptr = base, base + 4 * C, base + 8 * C
+        gg = H.gemm_geom()
+        # S[b,h] = Q K^T : A = q rows (pitch 3C), B = k rows [N][hd] (pitch 3C)
+        gemm(q_ptr, C3, k_ptr, C3, 0, P(S), N, N, N, hd, hd, gg, Z=Z, Zi=heads, sA=(N * C3, hd), sB=(N * C3, hd), sC=(heads * N * N, N * N))
+        check(lib().corrif_softmax_rows(P(S), Z * N, N, scale, stream()), "corrif_softmax_rows")
+        drop = training and p_drop > 0.0
+        Pd = S
+        seed = off = 0
+        if drop:
+            seed, off = _Philox.reserve(S.numel())
+            Pd = torch.empty_like(S)
+            check(lib().corrif_dropout(P(S), P(Pd), S.numel(), p_drop, seed, off, stream()), "corrif_dropout")
+        out = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        # O[b,:,h,:] = P V : B operand is V as [K = tokens][N = hd] (layout 1, pitch 3C)
+        gemm(P(Pd), N, v_ptr, C3, 1, P(out), C, N, hd, N, N, gg, Z=Z, Zi=heads, sA=(heads * N * N, N * N), sB=(N * C3, hd), sC=(N * C, hd))
+        ctx.save_for_backward(qkv, S)
+        ctx.cfg = (heads, p_drop, drop, seed, off, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        qkv, S = ctx.saved_tensors
+        heads, p_drop, drop, seed, off, scale = ctx.cfg
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        hd = C // heads
+        dev = qkv.device
+        Z = B * heads
+        go = go.contiguous()
+        base = qkv.data_ptr()
+        q_ptr, k_ptr, v_ptr = base, base + 4 * C, base + 8 * C
+        dqkv = torch.empty_like(qkv)
+        dbase = dqkv.data_ptr()
+        dq_ptr, dk_ptr, dv_ptr = dbase, dbase + 4 * C, dbase + 8 * C
+        gg = H.gemm_geom()
+        Pd = S
+        if drop:
+            Pd = torch.empty_like(S)
+            check(lib().corrif_dropout(P(S), P(Pd), S.numel(), p_drop, seed, off, stream()), "corrif_dropout")
+        # dV[m, d] = sum_n P'[n, m] dO[n, d]
+        wgrad(P(Pd), N, P(go), C, hd, dv_ptr, C3, N, N, hd, gg, dev, Z=Z, Zi=heads, sA=(heads * N * N, N * N), sB=(N * C, hd), sC=(N * C3, hd))
+        # dP' = dO V^T  (reuse the P' buffer when it is a private copy)
+        dP = Pd if drop else torch.empty_like(S)
+        gemm(P(go), C, v_ptr, C3, 0, P(dP), N, N, N, hd, hd, gg, Z=Z, Zi=heads, sA=(N * C, hd), sB=(N * C3, hd), sC=(heads * N * N, N * N))
+        if drop:
+            check(lib().corrif_dropout(P(dP), P(dP), dP.numel(), p_drop, seed, off, stream()), "corrif_dropout")
+        check(lib().corrif_softmax_rows_bwd(P(S), P(dP), Z * N, N, scale, stream()), "corrif_softmax_rows_bwd")
+        # dQ = dS K ; dK = dS^T Q
+        gemm(P(dP), N, k_ptr, C3, 1, dq_ptr, C3, N, hd, N, N, gg, Z=Z, Zi=heads, sA=(heads * N * N, N * N), sB=(N * C3, hd), sC=(N * C3, hd))
+        wgrad(P(dP), N, q_ptr, C3, hd, dk_ptr, C3, N, N, hd, gg, dev, Z=Z, Zi=heads, sA=(heads * N * N, N * N), sB=(N * C3, hd), sC=(N * C3, hd))
+        return dqkv, None, None, None
+
+
+def attention(qkv, heads, p_drop, training):
+    return AttentionFn.apply(qkv, heads, p_drop, training)
+
+
+# --------------------------------------------------------------------------------------- inter-modal correlation
+class InterCorrFn(Function):
+    @staticmethod
+    def forward(ctx, a, b, c):
+        a, b, c = a.contiguous(), b.contiguous(), c.contiguous()
+        B, S, C3 = a.shape
+        C = C3 // 3
+        outs = [torch.empty((B, S, C), dtype=torch.float32, device=a.device) for _ in range(3)]
+        check(lib().corrif_intercorr_fwd(P(a), P(b), P(c), C3, P(outs[0]), P(outs[1]), P(outs[2]), C, B, S, C, stream()), "corrif_intercorr_fwd")
+        ctx.save_for_backward(a, b, c)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        a, b, c = ctx.saved_tensors
+        B, S, C3 = a.shape
+        C = C3 // 3
+        gs = [g.contiguous() if g is not None else torch.zeros((B, S, C), dtype=torch.float32, device=a.device) for g in (g0, g1, g2)]
+        ds = [torch.empty_like(a) for _ in range(3)]
+        check(lib().corrif_intercorr_bwd(P(a), P(b), P(c), C3, P(gs[0]), P(gs[1]), P(gs[2]), C, P(ds[0]), P(ds[1]), P(ds[2]), B, S, C, stream()),
+              "corrif_intercorr_bwd")
+        return tuple(ds)
+
+
+inter_corr = InterCorrFn.apply
+
+
+# --------------------------------------------------------------------------------------- pooling / resampling
+class MaxPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, D, Hh, W, C = x.shape
+        Ho, Wo = (Hh - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((B, D, Ho, Wo, C), dtype=torch.float32, device=x.device)
+        idx = torch.empty((B, D, Ho, Wo, C), dtype=torch.int8, device=x.device)
+        check(lib().corrif_maxpool133_fwd(P(x), P(y), P(idx), B, D, Hh, W, C, stream()), "corrif_maxpool133_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, D, Hh, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, D, Hh, W, C = ctx.shape
+        g = g.contiguous()
+        gx = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        check(lib().corrif_maxpool133_bwd(P(g), P(idx), P(gx), B, D, Hh, W, C, stream()), "corrif_maxpool133_bwd")
+        return gx
+
+
+maxpool133 = MaxPoolFn.apply
+
+
+class ResampleFn(Function):
+    @staticmethod
+    def forward(ctx, x, size, mode, out):
+        x, _, ldx = rows_view(x)
+        B, Di, Hi, Wi, C = x.shape
+        Do, Ho, Wo = size
+        if out is None:
+            out = torch.empty((B, Do, Ho, Wo, C), dtype=torch.float32, device=x.device)
+        y, _, ldy = rows_view(out)
+        assert y is out
+        fn = lib().corrif_trilinear_fwd if mode == "trilinear" else lib().corrif_nearest_fwd
+        check(fn(P(x), ldx, P(y), ldy, B, C, Di, Hi, Wi, Do, Ho, Wo, stream()), "corrif_%s_fwd" % mode)
+        ctx.cfg = (mode, (B, Di, Hi, Wi, C), size)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mode, (B, Di, Hi, Wi, C), (Do, Ho, Wo) = ctx.cfg
+        g, _, ldg = rows_view(g)
+        gx = torch.empty((B, Di, Hi, Wi, C), dtype=torch.float32, device=g.device)
+        fn = lib().corrif_trilinear_bwd if mode == "trilinear" else lib().corrif_nearest_bwd
+        check(fn(P(g), ldg, P(gx), C, B, C, Di, Hi, Wi, Do, Ho, Wo, stream()), "corrif_%s_bwd" % mode)
+        return gx, None, None, None
+
+
+def trilinear(x, size, out=None):
+    return ResampleFn.apply(x, tuple(size), "trilinear", out)
+
+
+def nearest(x, size, out=None):
+    return ResampleFn.apply(x, tuple(size), "nearest", out)
+
+
+# --------------------------------------------------------------------------------------- concatenation
+class CatChannelsFn(Function):
+    """torch.cat(dim=channels) whose parts were written in place into channel slices of `buf` by their producers."""
+
+    @staticmethod
+    def forward(ctx, holder, *parts):
+        ctx.widths = [p.shape[-1] for p in parts]
+        buf = holder[0]
+        return buf.view(buf.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, o = [], 0
+        for w in ctx.widths:
+            outs.append(g[..., o:o + w])
+            o += w
+        return (None,) + tuple(outs)
+
+
+def cat_channels(buf, *parts):
+    return CatChannelsFn.apply([buf], *parts)
+
+
+class CatTokensFn(Function):
+    """torch.cat(dim=1) of [B, n_i, C] token blocks (mmvit4.py:515-521)."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        parts = [p.contiguous() for p in parts]
+        B, C = parts[0].shape[0], parts[0].shape[-1]
+        ns = [p.shape[1] for p in parts]
+        Nt = sum(ns)
+        buf = torch.empty((B, Nt, C), dtype=torch.float32, device=parts[0].device)
+        o = 0
+        for p_, n in zip(parts, ns):
+            check(lib().corrif_copy2d(P(p_), n * C, buf.data_ptr() + 4 * o * C, Nt * C, B, n * C, 0, stream()), "corrif_copy2d")
+            o += n
+        ctx.ns = ns
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        B, Nt, C = g.shape
+        outs, o = [], 0
+        for n in ctx.ns:
+            t = torch.empty((B, n, C), dtype=torch.float32, device=g.device)
+            check(lib().corrif_copy2d(g.data_ptr() + 4 * o * C, Nt * C, P(t), n * C, B, n * C, 0, stream()), "corrif_copy2d")
+            outs.append(t)
+            o += n
+        return tuple(outs)
+
+
+cat_tokens = CatTokensFn.apply
+
+
+# --------------------------------------------------------------------------------------- head / loss / metric
+class HeadFn(Function):
+    """final_conv (8 -> 3, 1x1x1, bias) + sigmoid; channels-last [B,1,224,224,8] -> NCDHW [B,3,1,224,224]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        B = x.shape[0]
+        HW = x.numel() // (B * 8)
+        pred = torch.empty((B, 3, 1, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+        check(lib().corrif_head_fwd(P(x), P(weight), P(bias), P(pred), B, HW, stream()), "corrif_head_fwd")
+        ctx.save_for_backward(x, weight, pred)
+        return pred
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, pred = ctx.saved_tensors
+        B = x.shape[0]
+        HW = x.numel() // (B * 8)
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        gw = torch.empty_like(weight)
+        gb = torch.empty(3, dtype=torch.float32, device=x.device)
+        ws = _ws(lib().corrif_head_workspace(B, HW), x.device)
+        check(lib().corrif_head_bwd(P(g), P(pred), P(x), P(weight), P(gx), P(gw), P(gb), P(ws), B, HW, stream()), "corrif_head_bwd")
+        return gx, gw, gb
+
+
+head = HeadFn.apply
+
+
+class BCEWithLogitsMeanFn(Function):
+    """nn.BCEWithLogitsLoss()(pred, target) as called at F4_TRAIN.py:58-60."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred, target = pred.contiguous(), target.contiguous()
+        n = pred.numel()
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        dpred = torch.empty_like(pred)
+        ws = _ws(lib().corrif_bce_workspace(n), pred.device)
+        check(lib().corrif_bce_logits_mean(P(pred), P(target), n, P(loss), P(dpred), P(ws), stream()), "corrif_bce_logits_mean")
+        ctx.save_for_backward(dpred)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        out = torch.empty_like(dpred)
+        check(lib().corrif_scale_dev(P(dpred), P(g.contiguous()), P(out), dpred.numel(), stream()), "corrif_scale_dev")
+        return out, None
+
+
+bce_with_logits_mean = BCEWithLogitsMeanFn.apply
+
+
+def jaccard_all(y, y_pred, eps=1e-8):
+    """returns a [3] tensor: Jaccard2, Jaccard, JaccardAndF1 (F5_JACCARD2.py:4-37) for y, y_pred of n elements"""
+    y, y_pred = y.contiguous(), y_pred.contiguous()
+    n = y.numel()
+    out = torch.empty(3, dtype=torch.float32, device=y.device)
+    ws = _ws(lib().corrif_jaccard_workspace(n), y.device)
+    check(lib().corrif_jaccard(P(y), P(y_pred), n, eps, P(out), P(ws), stream()), "corrif_jaccard")
+    return out

@@ -198,8 +198,11 @@ int corrif_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, 
 /* element-wise helpers (aten::add / gelu_backward / mul): y = a + b ; dx = dy * gelu'(x) */
 int corrif_add(const float* a, const float* b, float* y, int64_t n, void* stream);
 int corrif_add_bcast_rows(const float* a, const float* b, int64_t b_n, float* y, int64_t n, void* stream); /* b index = i % b_n */
+int corrif_gelu_fwd(const float* x, float* y, int64_t n, void* stream);   /* exact erf GELU, mmvit4.py:341-345 */
 int corrif_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
 int corrif_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+/* y = x * scalar[0], scalar on the device (upstream gradient of the scalar loss) */
+int corrif_scale_dev(const float* x, const float* scalar, float* y, int64_t n, void* stream);
 /* strided 2-D copy / accumulate: dst[r*ldd + c] (+)= src[r*lds + c], c < C (torch.cat / chunk grads) */
 int corrif_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int32_t C, int32_t accumulate, void* stream);
 /* out[c] = sum over rows r of x[r*ld + c] for r in a group of `rows` (pos gradient: sum over batch) */

@@ -1,0 +1,395 @@
+"""GPU parity tests, kernel family by kernel family: every C-ABI entry (through the ctypes host layer) against the
+stock-PyTorch CPU statement of the same ATen op the reference uses.  fp32; tolerances are written in each test."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    import ops as _ops
+    _ops.lib()           # raises if libcorrif_gfx950.so is missing: no fall-back
+    return _ops
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def cl(t):      # NCDHW -> channels-last dense
+    return t.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def ncdhw(t):
+    return t.permute(0, 4, 1, 2, 3)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+CONVS = [
+    # name, Ci, Co, k, stride, pad, replicate, (B, D, H, W), bias
+    ("gemm_1x1", 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 3, 14, 14), False),
+    ("1x1_ktail_184", 184, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 8, 8, 8), True),
+    ("1x1_stride2", 64, 96, (1, 1, 1), (1, 2, 2), (0, 0, 0), False, (2, 3, 14, 14), False),
+    ("1x3x3", 32, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), False, (2, 3, 14, 14), False),
+    ("1x3x3_stride2", 32, 48, (1, 3, 3), (1, 2, 2), (0, 1, 1), False, (2, 3, 14, 14), False),
+    ("1x3x3_stride2_odd", 32, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1), False, (1, 2, 7, 7), False),
+    ("3x3x3_zero", 24, 24, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, (2, 4, 9, 10), True),
+    ("3x3x3_rep_small_n", 32, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (2, 8, 8, 8), True),
+    ("3x3x3_rep_320", 320, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (1, 6, 6, 6), True),
+    ("1x1_n8", 8, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 6, 6, 6), True),
+    ("1x1_wide", 2048, 192, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (1, 4, 4, 4), True),
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS, ids=[c[0] for c in CONVS])
+def test_conv3d(ops, cfg):
+    name, Ci, Co, k, stride, pad, rep, (B, D, Hh, W), bias = cfg
+    x = rnd(B, Ci, D, Hh, W, seed=1)
+    w = rnd(Co, Ci, *k, seed=2, scale=1.0 / math.sqrt(Ci * k[0] * k[1] * k[2]))
+    b = rnd(Co, seed=3) if bias else None
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if bias else None
+    if rep:
+        yr = F.conv3d(F.pad(xr, (1, 1, 1, 1, 1, 1), mode="replicate"), wr, br, stride)
+    else:
+        yr = F.conv3d(xr, wr, br, stride, pad)
+    gy = rnd(*yr.shape, seed=4)
+    yr.backward(gy)
+    xg = cl(x).to(DEV).requires_grad_()
+    wg = w.to(DEV).requires_grad_()
+    bg = b.to(DEV).requires_grad_() if bias else None
+    yg = ops.conv3d(xg, wg, bg, stride, pad, rep)
+    yg.backward(cl(gy).to(DEV))
+    torch.cuda.synchronize()
+    assert rel(ncdhw(yg), yr) < 2e-6, "forward"
+    assert rel(ncdhw(xg.grad), xr.grad) < 2e-6, "data gradient"
+    assert rel(wg.grad, wr.grad) < 2e-6, "weight gradient"
+    if bias:
+        assert rel(bg.grad, br.grad) < 2e-6, "bias gradient"
+
+
+def test_conv3d_sliced_io(ops):
+    """input is a channel slice of a wider buffer and the output is written into a slice (in-place concat)."""
+    B, D, Hh, W, Ci, Co = 2, 3, 6, 6, 16, 24
+    x = rnd(B, Ci, D, Hh, W, seed=5)
+    w = rnd(Co, Ci, 1, 1, 1, seed=6, scale=0.25)
+    wide = torch.zeros(B, D, Hh, W, 40, device=DEV)
+    wide[..., 8:24] = cl(x).to(DEV)
+    out = torch.full((B, D, Hh, W, 72), 7.0, device=DEV)
+    y = ops.conv3d(wide[..., 8:24], w.to(DEV), None, (1, 1, 1), (0, 0, 0), False, out[..., 24:48])
+    torch.cuda.synchronize()
+    assert y.data_ptr() == out[..., 24:48].data_ptr()
+    assert rel(ncdhw(out[..., 24:48]), F.conv3d(x, w)) < 2e-6
+    assert (out[..., :24] == 7).all() and (out[..., 48:] == 7).all()
+
+
+def test_stem_conv(ops):
+    B, D, Hh, W = 2, 3, 30, 34
+    xin = rnd(B, 3, D, Hh, W, seed=7)
+    w = rnd(64, 1, 3, 7, 7, seed=8, scale=1 / 12.0)
+    wr = w.clone().requires_grad_()
+    yr = F.conv3d(xin[:, 1:2], wr, None, (1, 2, 2), (1, 3, 3))
+    gy = rnd(*yr.shape, seed=9)
+    yr.backward(gy)
+    wg = w.to(DEV).requires_grad_()
+    yg = ops.conv3d(xin.to(DEV)[:, 1], wg, None, (1, 2, 2), (1, 3, 3))
+    yg.backward(cl(gy).to(DEV))
+    torch.cuda.synchronize()
+    assert rel(ncdhw(yg), yr) < 2e-6
+    assert rel(wg.grad, wr.grad) < 2e-6
+
+
+def test_linear(ops):
+    x = rnd(3, 70, 512, seed=1)
+    w = rnd(1536, 512, seed=2, scale=0.05)
+    b = rnd(1536, seed=3)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.linear(xr, wr, br)
+    gy = rnd(*yr.shape, seed=4)
+    yr.backward(gy)
+    xg, wg, bg = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    yg = ops.linear(xg, wg, bg)
+    yg.backward(gy.to(DEV))
+    torch.cuda.synchronize()
+    for a, r in ((yg, yr), (xg.grad, xr.grad), (wg.grad, wr.grad), (bg.grad, br.grad)):
+        assert rel(a, r) < 2e-6
+
+
+@pytest.mark.parametrize("relu_in,relu_out,res,C,training", [(False, True, False, 64, True), (False, True, True, 256, True),
+                                                               (True, False, False, 64, True), (False, False, False, 2048, True),
+                                                               (False, True, True, 128, False)])
+def test_batch_norm(ops, relu_in, relu_out, res, C, training):
+    B, D, Hh, W = 2, 3, 7, 9
+    x = rnd(B, C, D, Hh, W, seed=1) * 2 + 0.5
+    gamma, beta = 0.5 + torch.rand(C, generator=torch.Generator().manual_seed(2)), rnd(C, seed=3, scale=0.2)
+    rm, rv = rnd(C, seed=4, scale=0.1), 0.5 + torch.rand(C, generator=torch.Generator().manual_seed(5))
+    r = rnd(B, C, D, Hh, W, seed=6) if res else None
+    xr, gr, br = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    rr = r.clone().requires_grad_() if res else None
+    rm_r, rv_r = rm.clone(), rv.clone()
+    t = F.relu(xr) if relu_in else xr
+    yr = F.batch_norm(t, rm_r, rv_r, gr, br, training, 0.1, 1e-5)
+    if res:
+        yr = yr + rr
+    if relu_out:
+        yr = F.relu(yr)
+    gy = rnd(*yr.shape, seed=7)
+    yr.backward(gy)
+    xg, gg, bg = cl(x).to(DEV).requires_grad_(), gamma.to(DEV).requires_grad_(), beta.to(DEV).requires_grad_()
+    rg = cl(r).to(DEV).requires_grad_() if res else None
+    rm_g, rv_g = rm.to(DEV), rv.to(DEV)
+    yg = ops.batch_norm(xg, gg, bg, rm_g, rv_g, rg, relu_in, relu_out, training, 0.1, 1e-5)
+    yg.backward(cl(gy).to(DEV))
+    torch.cuda.synchronize()
+    assert rel(ncdhw(yg), yr) < 2e-6
+    assert rel(ncdhw(xg.grad), xr.grad) < 1e-5
+    assert rel(gg.grad, gr.grad) < 1e-5 and rel(bg.grad, br.grad) < 1e-5
+    if res:
+        assert rel(ncdhw(rg.grad), rr.grad) < 1e-6
+    assert rel(rm_g, rm_r) < 1e-6 and rel(rv_g, rv_r) < 1e-6          # running statistics (momentum 0.1, unbiased var)
+
+
+@pytest.mark.parametrize("C,shape", [(24, (2, 3, 10, 10)), (192, (3, 8, 8, 8)), (8, (2, 16, 16, 16))])
+def test_relu_instnorm(ops, C, shape):
+    B, D, Hh, W = shape
+    x = rnd(B, C, D, Hh, W, seed=1) + 0.3
+    xr = x.clone().requires_grad_()
+    yr = F.instance_norm(F.relu(xr), eps=1e-5)
+    gy = rnd(*yr.shape, seed=2)
+    yr.backward(gy)
+    xg = cl(x).to(DEV).requires_grad_()
+    out = torch.zeros(B, D, Hh, W, C + 16, device=DEV)
+    yg = ops.relu_instnorm(xg, 1e-5, out[..., 8:8 + C])
+    yg.backward(cl(gy).to(DEV))
+    torch.cuda.synchronize()
+    assert rel(ncdhw(out[..., 8:8 + C]), yr) < 2e-6
+    assert rel(ncdhw(xg.grad), xr.grad) < 1e-5
+
+
+def test_layer_norm_with_pos(ops):
+    B, N, C = 3, 40, 512
+    x, pos = rnd(B, N, C, seed=1), rnd(1, N, C, seed=2, scale=0.1)
+    g, b = 0.5 + torch.rand(C, generator=torch.Generator().manual_seed(3)), rnd(C, seed=4, scale=0.1)
+    xr, pr, gr, br = [t.clone().requires_grad_() for t in (x, pos, g, b)]
+    xs_r = xr + pr
+    yr = F.layer_norm(xs_r, (C,), gr, br, 1e-5)
+    g1, g2 = rnd(B, N, C, seed=5), rnd(B, N, C, seed=6)
+    (yr * g1 + xs_r * g2).sum().backward()
+    xg, pg, gg, bg = [t.to(DEV).requires_grad_() for t in (x, pos, g, b)]
+    xs, y = ops.layer_norm(xg, gg, bg, pos=pg)
+    torch.autograd.backward([y, xs], [g1.to(DEV), g2.to(DEV)])
+    torch.cuda.synchronize()
+    assert rel(y, yr) < 2e-6 and rel(xs, xs_r) < 1e-7
+    assert rel(xg.grad, xr.grad) < 1e-5 and rel(pg.grad, pr.grad) < 1e-5
+    assert rel(gg.grad, gr.grad) < 1e-5 and rel(bg.grad, br.grad) < 1e-5
+    # plain form
+    x2 = x.to(DEV).requires_grad_()
+    y2 = ops.layer_norm(x2, gg.detach(), bg.detach())
+    assert rel(y2, F.layer_norm(x, (C,), g, b, 1e-5)) < 2e-6
+
+
+def test_maxpool_with_ties(ops):
+    B, C, D, Hh, W = 2, 64, 3, 13, 14
+    x = torch.relu(rnd(B, C, D, Hh, W, seed=1)) * 0.5 + 0.25          # many exact ties (the stem is ReLU -> BN -> pool)
+    xr = x.clone().requires_grad_()
+    yr = F.max_pool3d(xr, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    gy = rnd(*yr.shape, seed=2)
+    yr.backward(gy)
+    xg = cl(x).to(DEV).requires_grad_()
+    yg = ops.maxpool133(xg)
+    yg.backward(cl(gy).to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(ncdhw(yg).cpu(), yr.detach())
+    assert rel(ncdhw(xg.grad), xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("src,dst", [((4, 14, 14), (8, 8, 8)), ((3, 56, 56), (8, 8, 8)), ((8, 8, 8), (16, 16, 16)),
+                                      ((12, 12, 12), (1, 21, 21)), ((4, 7, 7), (8, 8, 8)), ((1, 5, 5), (8, 8, 8))])
+def test_trilinear(ops, src, dst):
+    B, C = 2, 16
+    x = rnd(B, C, *src, seed=1)
+    xr = x.clone().requires_grad_()
+    yr = F.interpolate(xr, size=dst, mode="trilinear", align_corners=True)
+    gy = rnd(*yr.shape, seed=2)
+    yr.backward(gy)
+    xg = cl(x).to(DEV).requires_grad_()
+    yg = ops.trilinear(xg, dst)
+    yg.backward(cl(gy).to(DEV))
+    torch.cuda.synchronize()
+    assert rel(ncdhw(yg), yr) < 1e-6
+    assert rel(ncdhw(xg.grad), xr.grad) < 2e-6
+
+
+def test_trilinear_scale2_equals_upsample(ops):
+    x = rnd(1, 8, 16, 16, 16, seed=3)
+    yr = torch.nn.Upsample(scale_factor=2, mode="trilinear", align_corners=True)(x)
+    yg = ops.trilinear(cl(x).to(DEV), (32, 32, 32))
+    assert rel(ncdhw(yg), yr) < 1e-6
+
+
+@pytest.mark.parametrize("src,dst", [((4, 14, 14), (16, 16, 16)), ((3, 28, 28), (32, 32, 32)), ((4, 56, 56), (20, 128, 128))])
+def test_nearest(ops, src, dst):
+    B, C = 2, 24
+    x = rnd(B, C, *src, seed=1)
+    xr = x.clone().requires_grad_()
+    yr = F.interpolate(xr, dst)
+    gy = rnd(*yr.shape, seed=2)
+    yr.backward(gy)
+    xg = cl(x).to(DEV).requires_grad_()
+    yg = ops.nearest(xg, dst)
+    yg.backward(cl(gy).to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(ncdhw(yg).cpu(), yr.detach())
+    assert rel(ncdhw(xg.grad), xr.grad) < 2e-6
+
+
+@pytest.mark.parametrize("B,N", [(2, 512), (1, 2048)])
+def test_attention(ops, B, N):
+    heads, C = 8, 512
+    qkv = rnd(B, N, 3 * C, seed=1, scale=0.5)
+    qr = qkv.clone().requires_grad_()
+    q, k, v = qr.reshape(B, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+    a = torch.softmax((q @ k.transpose(-2, -1)) * (C // heads) ** -0.5, -1)
+    outr = (a @ v).transpose(1, 2).reshape(B, N, C)
+    go = rnd(B, N, C, seed=2)
+    outr.backward(go)
+    qg = qkv.to(DEV).requires_grad_()
+    og = ops.attention(qg, heads, 0.1, False)
+    og.backward(go.to(DEV))
+    torch.cuda.synchronize()
+    assert rel(og, outr) < 3e-6
+    assert rel(qg.grad, qr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 4])
+def test_inter_corr(ops, B):
+    from oracle import mmvit4_oracle as O
+    S, C = 512, 512
+    qkvs = [rnd(B, S, 3 * C, seed=10 + i) for i in range(3)]
+    refs = [t.clone().requires_grad_() for t in qkvs]
+
+    def vol(t):       # [B,S,C] tokens -> [B,C,8,8,8]
+        return t.reshape(B, 8, 8, 8, C).permute(0, 4, 1, 2, 3)
+
+    q = [vol(t[..., :C]) for t in refs]
+    k = [vol(t[..., C:2 * C]) for t in refs]
+    v = [vol(t[..., 2 * C:]) for t in refs]
+    outs_r = [O.inter_corr(q[m], k, v).permute(0, 2, 3, 4, 1).reshape(B, S, C) for m in range(3)]
+    gs = [rnd(B, S, C, seed=20 + i) for i in range(3)]
+    torch.autograd.backward(outs_r, gs)
+    gin = [t.to(DEV).requires_grad_() for t in qkvs]
+    outs = ops.inter_corr(*gin)
+    torch.autograd.backward(list(outs), [g.to(DEV) for g in gs])
+    torch.cuda.synchronize()
+    for m in range(3):
+        assert rel(outs[m], outs_r[m]) < 2e-6
+        assert rel(gin[m].grad, refs[m].grad) < 1e-5
+
+
+def test_dropout_stream(ops):
+    x = torch.ones(1 << 20, device=DEV).requires_grad_()
+    ops.manual_seed(123)
+    y = ops.dropout(x, 0.1, True)
+    y.backward(torch.ones_like(y))
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.9) < 2e-3                                   # Bernoulli(0.9), n = 1M: sigma = 3e-4
+    assert torch.allclose(y[y != 0], torch.tensor(1 / 0.9, device=DEV))
+    assert torch.equal(x.grad, y.detach())                          # backward regenerates the same mask
+    ops.manual_seed(123)
+    assert torch.equal(ops.dropout(x.detach(), 0.1, True), y.detach())
+    y2 = ops.dropout(x.detach(), 0.1, True)                         # the stream advances: a different mask
+    assert not torch.equal(y2, y.detach())
+    assert ops.dropout(x, 0.1, False) is x                          # eval: identity
+    # lag-1 autocorrelation of the mask ~ 0
+    m = (y.detach() != 0).float() - keep
+    assert abs((m[1:] * m[:-1]).mean().item()) < 1e-3
+
+
+def test_add_gelu_cat(ops):
+    a, b = rnd(2, 64, 512, seed=1), rnd(2, 64, 512, seed=2)
+    ag = a.to(DEV).requires_grad_()
+    y = ops.gelu(ops.add(ag, b.to(DEV)))
+    ar = a.clone().requires_grad_()
+    yr = F.gelu(ar + b)
+    g = rnd(2, 64, 512, seed=3)
+    y.backward(g.to(DEV))
+    yr.backward(g)
+    assert rel(y, yr) < 1e-6 and rel(ag.grad, ar.grad) < 1e-6
+    parts = [rnd(2, n, 512, seed=4 + i) for i, n in enumerate((512, 512, 512, 512))]
+    pg = [p.to(DEV).requires_grad_() for p in parts]
+    c = ops.cat_tokens(*pg)
+    assert torch.equal(c.cpu(), torch.cat(parts, 1))
+    gg = rnd(2, 2048, 512, seed=9)
+    c.backward(gg.to(DEV))
+    assert torch.equal(pg[2].grad.cpu(), gg[:, 1024:1536])
+
+
+def test_head_and_loss(ops):
+    B = 2
+    x = rnd(B, 1, 224, 224, 8, seed=1)
+    w, b = rnd(3, 8, 1, 1, 1, seed=2, scale=0.4), rnd(3, seed=3, scale=0.1)
+    _, mask = helpers.make_inputs(B, 3, 8, 8)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    pr = torch.sigmoid(F.conv3d(xr.permute(0, 4, 1, 2, 3), wr, br))
+    lr = F.binary_cross_entropy_with_logits(pr, mask)
+    lr.backward()
+    xg, wg, bg = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    pg = ops.head(xg, wg, bg)
+    lg = ops.bce_with_logits_mean(pg, mask.to(DEV))
+    lg.backward()
+    torch.cuda.synchronize()
+    assert pg.shape == (B, 3, 1, 224, 224)
+    assert rel(pg, pr) < 1e-6 and abs(lg.item() - lr.item()) < 1e-6
+    assert rel(xg.grad, xr.grad) < 1e-5 and rel(wg.grad, wr.grad) < 1e-5 and rel(bg.grad, br.grad) < 1e-5
+
+
+def test_jaccard_matches_reference_fixture(ops):
+    """F5_JACCARD2.py through the device kernel: bit-identical on 0/1 masks, 1e-6 on soft predictions."""
+    g = np.load(os.path.join(helpers.GOLDEN, "jaccard.npz"))
+    gen = torch.Generator().manual_seed(7)
+    n = 2 * 224 * 224
+    y = (torch.rand(n, 1, generator=gen) > 0.6).float()
+    soft = torch.rand(n, 1, generator=gen)
+    hard = (soft > 0.5).float()
+    zero = torch.zeros(n, 1)
+    cases = {"soft": (y, soft), "hard": (y, hard), "allzero_mask": (zero, soft), "allzero_hard": (zero, hard), "perfect": (y, y.clone())}
+    for nm, (a, b) in cases.items():
+        out = ops.jaccard_all(a.to(DEV), b.to(DEV)).cpu().numpy()
+        exact = nm in ("hard", "allzero_hard", "perfect")
+        for i, key in enumerate(("j2_", "j1_", "f1_")):
+            ref = g[key + nm]
+            if exact:
+                assert out[i] == ref[0], (nm, key, out[i], ref)        # integer partial sums: bit-identical
+            else:
+                assert abs(out[i] - ref[0]) <= 1e-6 * max(1.0, abs(ref[0])), (nm, key)
+
+
+def test_adam_matches_torch(ops):
+    p0, g0 = rnd(1000, seed=1), rnd(1000, seed=2)
+    pr = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    p = p0.to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        pr.grad = g0 * step
+        opt.step()
+        helpers_status = ops.lib().corrif_adam_step(p.data_ptr(), (g0 * step).to(DEV).data_ptr(), m.data_ptr(), v.data_ptr(), 1000, 1e-3, 0.9,
+                                                    0.999, 1e-8, 0.0, step, ops.stream())
+        assert helpers_status == 0
+    torch.cuda.synchronize()
+    assert rel(p, pr) < 1e-6
