@@ -1,0 +1,188 @@
+"""Throughput of the MMVit4 hot path (forward + loss + backward) on N MI355X GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One JSON line on rank 0.  metric = images/s for one forward + backward of MMVit4 (BASELINE.json), workload = config 2:
+4 bands per modality group, 224x224, batch 32 per GPU, fp32, train mode (batch-stat BatchNorm, dropout on), synthetic
+inputs resident in HBM, random-init weights.  N > 1: weak scaling, one replica per GPU on its own 32-image shard, gradients
+averaged with bucketed RCCL all-reduce (inside the timed region).
+
+roofline: the dominant kernel family is the fp32 MFMA implicit-GEMM (`gemm_fwd_kernel` / `wgrad_kernel`); `achieved` is the
+algorithmic FLOPs of those launches (2*M*N*K each, from the launch descriptors) divided by their summed duration measured
+with HIP events on the launch stream inside the timed region; peak = 157.3 TFLOP/s (fp32 matrix, MI355X_MICROARCH.md).
+cpu_baseline: the CPU oracle (stock-PyTorch restatement, bit-identical to the reference on CPU) timed on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "corrifnet-correlation-aware-interactive-fusion-multimodal-learning-for-multispectral-images_amd")
+for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3
+FLOP_PER_IMAGE_FWD_BWD = 645.9e9          # 215.3 GFLOP forward x 3 at D=4, 224^2
+
+
+class MfmaTimer:
+    """records (flops, start, stop) for every MFMA GEMM launch by wrapping ops.gemm / ops.wgrad"""
+
+    def __init__(self, ops):
+        self.ops, self.rec, self.on = ops, [], False
+        self._gemm, self._wgrad = ops.gemm, ops.wgrad
+        ops.gemm, ops.wgrad = self.gemm, self.wgrad
+
+    def _timed(self, fn, flops, a, kw):
+        if not self.on:
+            return fn(*a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **kw)
+        e1.record()
+        self.rec.append((flops, e0, e1))
+        return r
+
+    def gemm(self, *a, **kw):       # (A, lda, B, ldb, b_layout, C, ldc, M, N, K, ...)
+        return self._timed(self._gemm, 2.0 * a[7] * a[8] * a[9] * kw.get("Z", 1), a, kw)
+
+    def wgrad(self, *a, **kw):      # (A, lda, B, ldb, Cs, C, ldc, R, M, N, ...)
+        return self._timed(self._wgrad, 2.0 * a[7] * a[8] * a[9] * kw.get("Z", 1), a, kw)
+
+    def summary(self):
+        fl = sum(r[0] for r in self.rec)
+        ms = sum(r[1].elapsed_time(r[2]) for r in self.rec)
+        return fl, ms, len(self.rec)
+
+
+def cpu_baseline(B=2, D=4, HW=224, iters=2):
+    """bounded sample of the same workload on the host cores: the oracle's forward + loss + backward at batch B"""
+    from oracle import mmvit4_oracle as O
+    import helpers
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    m = O.MMVit4().train()
+    x, mask = helpers.make_inputs(B, D, HW, HW)
+    ts = []
+    for i in range(iters + 1):
+        t0 = time.time()
+        m.zero_grad(set_to_none=True)
+        O.train_step_loss(m(x), mask).backward()
+        ts.append(time.time() - t0)
+    best = min(ts[1:])
+    return {"value": round(B / best, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "oracle (CPU restatement of mmvit4.MMVit4, bit-identical to the reference on CPU) fwd+loss+bwd, "
+                      "train mode, B=%d D=%d %dx%d fp32, best of %d after 1 warm-up (%.1f s/step)" % (B, D, HW, HW, iters, best)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU (BASELINE config 2: 32)")
+    ap.add_argument("--bands", type=int, default=4)
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    import mmvit4
+    import ops
+    import helpers
+    from data_parallel import GradAllReducer, broadcast_module_state
+    ops.lib()                                           # fail loudly if the HIP library is missing
+    timer = None if args.no_kernel_timing else MfmaTimer(ops)
+
+    torch.manual_seed(0)
+    model = mmvit4.MMVit4().to(dev).train()
+    broadcast_module_state(model)
+    reducer = GradAllReducer(model)
+    B = args.batch
+    xg, maskg = helpers.make_inputs(B, args.bands, args.size, args.size, seed=1234 + rank)   # rank r's own shard
+    x, mask = xg.to(dev), maskg.to(dev)
+    ops.manual_seed(1234 + rank)
+
+    def step():
+        reducer.zero_grad()
+        pred = model(x)
+        loss = ops.bce_with_logits_mean(pred, mask)     # F4_TRAIN.py:58-60
+        loss.backward()
+        reducer.finish()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if timer:
+        timer.on = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if timer:
+        timer.on = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    if rank == 0:
+        out = {"metric": "images/sec fwd+bwd, 4-band 224x224 bs32", "value": round(value, 3), "unit": "images/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "mmvit4 CorrIFNet fwd+loss+bwd, %d bands/modality, %dx%d, batch %d per GPU, train mode "
+                                      "(BASELINE configs[1])" % (args.bands, args.size, args.size, B),
+                          "global_batch": world * B, "parallelism": "dp%d" % world, "loss": float(loss.item()),
+                          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2)}}
+        if timer:
+            fl, ms, n = timer.summary()
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                               "kernel": "gemm_fwd_kernel+wgrad_kernel (fp32 MFMA implicit GEMM)", "launches_per_step": n // args.steps,
+                               "mfma_ms_per_step": round(ms / args.steps, 3),
+                               "algorithmic_gflop_per_step": round(fl / args.steps / 1e9, 1),
+                               "whole_step_frac": round(FLOP_PER_IMAGE_FWD_BWD * B / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
