@@ -40,21 +40,34 @@ class MfmaTimer:
         self._gemm, self._wgrad = ops.gemm, ops.wgrad
         ops.gemm, ops.wgrad = self.gemm, self.wgrad
 
-    def _timed(self, fn, flops, a, kw):
+    def _timed(self, fn, flops, key, a, kw):
         if not self.on:
             return fn(*a, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         r = fn(*a, **kw)
         e1.record()
-        self.rec.append((flops, e0, e1))
+        self.rec.append((flops, e0, e1, key))
         return r
 
-    def gemm(self, *a, **kw):       # (A, lda, B, ldb, b_layout, C, ldc, M, N, K, ...)
-        return self._timed(self._gemm, 2.0 * a[7] * a[8] * a[9] * kw.get("Z", 1), a, kw)
+    def gemm(self, *a, **kw):       # (A, lda, B, ldb, b_layout, C, ldc, M, N, K, Cs, geom, ...)
+        key = ("gemm" if a[11].is_gemm else ("dgrad" if a[11].dir < 0 else "conv"), a[7], a[8], a[9], kw.get("Z", 1))
+        return self._timed(self._gemm, 2.0 * a[7] * a[8] * a[9] * kw.get("Z", 1), key, a, kw)
 
-    def wgrad(self, *a, **kw):      # (A, lda, B, ldb, Cs, C, ldc, R, M, N, ...)
-        return self._timed(self._wgrad, 2.0 * a[7] * a[8] * a[9] * kw.get("Z", 1), a, kw)
+    def wgrad(self, *a, **kw):      # (A, lda, B, ldb, Cs, C, ldc, R, M, N, geom, ...)
+        key = ("wgrad", a[7], a[8], a[9], kw.get("Z", 1))
+        return self._timed(self._wgrad, 2.0 * a[7] * a[8] * a[9] * kw.get("Z", 1), key, a, kw)
+
+    def by_shape(self):
+        agg = {}
+        for fl, e0, e1, key in self.rec:
+            d = agg.setdefault(key, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+            d[2] += fl
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        return [{"kind": k[0], "M_or_R": k[1], "N_or_M": k[2], "K_or_N": k[3], "Z": k[4], "calls": v[0], "ms": round(v[1], 3),
+                 "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else 0} for k, v in rows]
 
     def summary(self):
         fl = sum(r[0] for r in self.rec)
@@ -97,6 +110,7 @@ def main():
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--dump-shapes", default=None, help="write per-shape MFMA launch timings (JSON lines) to this file")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -177,6 +191,10 @@ def main():
                                "mfma_ms_per_step": round(ms / args.steps, 3),
                                "algorithmic_gflop_per_step": round(fl / args.steps / 1e9, 1),
                                "whole_step_frac": round(FLOP_PER_IMAGE_FWD_BWD * B / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+        if timer and args.dump_shapes:
+            with open(args.dump_shapes, "w") as f:
+                for r in timer.by_shape():
+                    f.write(json.dumps(r) + "\n")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -10,17 +10,8 @@
 // pair of ds_read_b128).  Activations are channels-last so a tap's channel run is contiguous: the
 // gather is done while staging global -> registers -> LDS, never as an im2col buffer.
 #include "common.h"
+#include "igemm_args.h"
 
-#define BK 32
-#define LDS_PITCH (BK + 4)   // floats; 144-byte rows keep the ds_read_b128 lane groups conflict-free
-
-struct GemmArgs {
-    const float* A; const float* B; float* C; const float* bias; const float* addend;
-    int64_t lda, ldb, ldc, ld_add;
-    int M, N, K, Cs4, act, b_layout, Zi;
-    int64_t sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
-    DevGeom g;
-};
 
 template <int BM, int BN, int WM, int WN, int VEC>
 __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
@@ -250,23 +241,25 @@ extern "C" int corrif_gemm_fwd(const CorrifGemm* p, void* stream) {
     a.g = make_devgeom(p->g, p->lda);
     hipStream_t s = (hipStream_t)stream;
     if (scalar) return launch_fwd<128, 64, 2, 2, 1>(a, p->Z, s);
+    if (p->N <= 16 && !(p->N & 3) && !(p->ldc & 3) && !((uintptr_t)p->C & 15) && !(p->sC_o & 3) && !(p->sC_i & 3) &&
+        (!p->addend || (!(p->ld_add & 3) && !((uintptr_t)p->addend & 15))))
+        return launch_smalln_fwd(a, p->Z, s);
     if (p->N <= 32) return launch_fwd<256, 32, 4, 1>(a, p->Z, s);
-    if (p->N <= 64) return launch_fwd<128, 64, 2, 2>(a, p->Z, s);
-    return launch_fwd<128, 128, 2, 2>(a, p->Z, s);
+    // enough workgroups to keep 256 CUs x 3-4 resident blocks busy: shrink the tile when M*N is small
+    auto tiles = [&](int bm, int bn) { return (int64_t)((p->M + bm - 1) / bm) * ((p->N + bn - 1) / bn) * p->Z; };
+    if (p->N <= 64) {
+        if (tiles(128, 64) >= 768) return launch_fwd<128, 64, 2, 2>(a, p->Z, s);
+        return launch_fwd<64, 64, 2, 2>(a, p->Z, s);
+    }
+    if (tiles(128, 128) >= 768) return launch_fwd<128, 128, 2, 2>(a, p->Z, s);
+    if (tiles(128, 64) >= 768) return launch_fwd<128, 64, 2, 2>(a, p->Z, s);
+    return launch_fwd<64, 64, 2, 2>(a, p->Z, s);
 }
 
 // ------------------------------------------------------------------------------------------------
 // W-type: contraction over rows.  LDS tiles are [32 rows][BM] and [32 rows][BN]; MFMA lane (i, h)
 // reads element [2s+h][i] of each (ds_read_b32, lanes consecutive -> conflict free).
 // ------------------------------------------------------------------------------------------------
-struct WgradArgs {
-    const float* A; const float* B; float* C; float* ws;
-    int64_t lda, ldb, ldc;
-    int R, M, N, Cs, splits, rows_per_split, Zi;
-    int64_t sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
-    DevGeom g;
-};
-
 template <int BM, int BN, int WM, int WN, int VEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -404,14 +397,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     }
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t n, int count,
-                                   int N, int64_t ldc) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// out[i] = sum_j ws[j*n + i] in a fixed order: block = 64 consecutive elements x 4 slab lanes (coalesced 256-B rows)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t n, int count,
+                                                          int N, int64_t ldc) {
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + e;
     float s = 0.f;
-    for (int j = 0; j < count; ++j) s += ws[(int64_t)j * n + i];
-    if (N > 0) { int64_t r = i / N; out[r * ldc + (i - r * N)] = s; }
-    else out[i] = s;
+    if (i < n)
+        for (int j = rl; j < count; j += 4) s += ws[(int64_t)j * n + i];
+    red[rl][e] = s;
+    __syncthreads();
+    if (rl == 0 && i < n) {
+        s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        if (N > 0) { int64_t r = i / N; out[r * ldc + (i - r * N)] = s; }
+        else out[i] = s;
+    }
 }
 
 static int pick_splits(int R, int M, int N, int BM, int BN) {
@@ -423,7 +424,10 @@ static int pick_splits(int R, int M, int N, int BM, int BN) {
     if (want > 4096) want = 4096;
     return (int)want;
 }
-static void wgrad_tile(int M, int& BM, int& BN) { BN = 128; BM = (M <= 32) ? 32 : 64; }
+static void wgrad_tile(int M, int& BM, int& BN) {
+    BM = (M <= 32) ? 32 : 64;
+    BN = (M <= 16 && !(M & 3)) ? 256 : 128;     // M <= 16: the 4x4x1 small-M kernel, 256-wide J tiles
+}
 
 extern "C" size_t corrif_wgrad_workspace(const CorrifWgrad* p) {
     if (!p || p->splits <= 1) return 0;
@@ -432,12 +436,13 @@ extern "C" size_t corrif_wgrad_workspace(const CorrifWgrad* p) {
 extern "C" int corrif_wgrad_plan(int32_t R, int32_t M, int32_t N) {
     int BM, BN;
     wgrad_tile(M, BM, BN);
+    if (BN == 256) BM = 16;
     return pick_splits(R, M, N, BM, BN);
 }
 
 extern "C" int corrif_slab_reduce(const float* ws, float* out, int64_t n, int32_t count, void* stream) {
     if (!ws || !out || n <= 0 || count <= 0) return CORRIF_EINVAL;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, out, n,
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, ws, out, n,
                        count, 0, (int64_t)0);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
@@ -469,17 +474,22 @@ extern "C" int corrif_wgrad(const CorrifWgrad* p, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int BM, BN;
     wgrad_tile(p->M, BM, BN);
+    if (scalar) { BM = 64; BN = 128; }
+    if (BN == 256) BM = 16;
     uint32_t tiles = (uint32_t)((p->M + BM - 1) / BM) * (uint32_t)((p->N + BN - 1) / BN);
     dim3 grid(tiles, 1, p->splits > 1 ? p->splits : p->Z);
     if (scalar) {
         grid.x = (uint32_t)((p->M + 63) / 64) * (uint32_t)((p->N + 127) / 128);
         hipLaunchKernelGGL((wgrad_kernel<64, 128, 2, 2, 1>), grid, dim3(256), 0, s, a);
+    } else if (BN == 256) {
+        int rc = launch_smallm_wgrad(a, (int)grid.z, s);
+        if (rc != CORRIF_OK) return rc;
     } else if (BM == 32) hipLaunchKernelGGL((wgrad_kernel<32, 128, 1, 4, 4>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wgrad_kernel<64, 128, 2, 2, 4>), grid, dim3(256), 0, s, a);
     CORRIF_CHECK_LAUNCH();
     if (p->splits > 1) {
         int64_t n = (int64_t)p->M * p->N;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p->ws, p->C, n, p->splits,
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, p->ws, p->C, n, p->splits,
                            p->N, p->ldc);
         CORRIF_CHECK_LAUNCH();
     }

@@ -1,0 +1,28 @@
+// Launch descriptors shared by the implicit-GEMM kernel files.
+#pragma once
+#include "common.h"
+
+#define BK 32
+#define LDS_PITCH (BK + 4)   // floats; 144-byte rows keep the ds_read_b128 lane groups conflict-free
+
+struct GemmArgs {
+    const float* A; const float* B; float* C; const float* bias; const float* addend;
+    int64_t lda, ldb, ldc, ld_add;
+    int M, N, K, Cs4, act, b_layout, Zi;
+    int64_t sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
+    DevGeom g;
+};
+
+
+struct WgradArgs {
+    const float* A; const float* B; float* C; float* ws;
+    int64_t lda, ldb, ldc;
+    int R, M, N, Cs, splits, rows_per_split, Zi;
+    int64_t sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
+    DevGeom g;
+};
+
+
+// small-N / small-M variants on v_mfma_f32_4x4x1_16b_f32 (igemm_small.hip)
+int launch_smalln_fwd(const GemmArgs& a, int Z, hipStream_t s);     // N <= 16, N % 4 == 0
+int launch_smallm_wgrad(const WgradArgs& a, int grid_z, hipStream_t s);   // M <= 16, M % 4 == 0

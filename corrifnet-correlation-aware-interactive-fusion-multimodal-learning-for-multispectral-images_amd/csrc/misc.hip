@@ -110,48 +110,6 @@ extern "C" int corrif_sum_groups(const float* x, float* out, int64_t group_elems
     return CORRIF_OK;
 }
 
-// ------------------------------------------------------------------ column sums (bias gradients)
-__global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __restrict__ x, int64_t ld, int64_t rows, int C,
-                                                              double* __restrict__ part, int64_t rows_per_block) {
-    // block (bx, by): rows [bx*rpb, ...), channels by*256 + tid
-    int c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= C) return;
-    int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block;
-    if (r1 > rows) r1 = rows;
-    double s = 0;
-    for (int64_t r = r0; r < r1; ++r) s += (double)x[r * ld + c];
-    part[(int64_t)blockIdx.x * C + c] = s;
-}
-__global__ void col_sum_final_kernel(const double* __restrict__ part, int nb, int C, float* __restrict__ out) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0;
-    for (int k = 0; k < nb; ++k) s += part[(int64_t)k * C + c];
-    out[c] = (float)s;
-}
-static int col_sum_blocks(int64_t rows, int64_t& rpb) {
-    int64_t nb = (rows + 63) / 64;
-    if (nb > 512) nb = 512;
-    if (nb < 1) nb = 1;
-    rpb = (rows + nb - 1) / nb;
-    return (int)((rows + rpb - 1) / rpb);
-}
-extern "C" size_t corrif_col_sum_workspace(int64_t rows, int32_t C) {
-    int64_t rpb;
-    return (size_t)col_sum_blocks(rows, rpb) * C * sizeof(double);
-}
-extern "C" int corrif_col_sum(const float* x, int64_t ld, int64_t rows, int32_t C, float* out, double* ws, void* stream) {
-    if (!x || !out || !ws || rows <= 0 || C <= 0) return CORRIF_EINVAL;
-    int64_t rpb;
-    int nb = col_sum_blocks(rows, rpb);
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(col_sum_partial_kernel, dim3(nb, (C + 255) / 256), dim3(256), 0, s, x, ld, rows, (int)C, ws, rpb);
-    CORRIF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(col_sum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)ws, nb, (int)C, out);
-    CORRIF_CHECK_LAUNCH();
-    return CORRIF_OK;
-}
-
 // ------------------------------------------------------------------ weight re-layouts
 __global__ void repack_kernel(const float* __restrict__ in, float* __restrict__ out, int O, int I, int T, int mode, int64_t ldo) {
     int64_t n = (int64_t)O * I * T;

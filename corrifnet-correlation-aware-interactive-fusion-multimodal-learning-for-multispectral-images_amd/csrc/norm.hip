@@ -31,7 +31,7 @@ extern "C" size_t corrif_norm_workspace(int64_t rows_per_group, int32_t G, int32
     return (size_t)G * n.chunks * C * 2 * sizeof(double) + (size_t)G * C * 2 * sizeof(float) + 64;
 }
 
-// partial[(g*chunks + chunk)*C*2 + c*2 + {0,1}]
+// partial[((g*C + c)*chunks + chunk)*2 + {0,1}]
 template <int MODE>   // 0: sum x', sum x'^2 ; 1: sum g, sum g*xhat
 __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
                                                            int64_t lddy, const float* __restrict__ y, int64_t ldy,
@@ -88,24 +88,33 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
         for (int k = 1; k < n.RL; ++k)
 #pragma unroll
             for (int e = 0; e < 4; ++e) { s0[e] += red[(k * n.CT + cl) * 8 + e]; s1[e] += red[(k * n.CT + cl) * 8 + 4 + e]; }
-        double* o = part + ((int64_t)(g * n.chunks + chunk) * C + c4 * 4) * 2;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { o[e * 2] = s0[e]; o[e * 2 + 1] = s1[e]; }
+        for (int e = 0; e < 4; ++e) {
+            double* o = part + (((int64_t)g * C + c4 * 4 + e) * n.chunks + chunk) * 2;
+            o[0] = s0[e];
+            o[1] = s1[e];
+        }
     }
 }
 
-__global__ void norm_stats_final_kernel(const double* __restrict__ part, int chunks, int G, int C, int64_t rows_per_group, float eps,
-                                        float* __restrict__ mean, float* __restrict__ rstd, float* running_mean,
-                                        float* running_var, float momentum) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per (group, channel): lanes stride over the chunk partials, fixed-order butterfly in double
+__device__ __forceinline__ void wave_sum2(double& a, double& b) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+}
+__global__ __launch_bounds__(256) void norm_stats_final_kernel(const double* __restrict__ part, int chunks, int G, int C,
+                                                               int64_t rows_per_group, float eps, float* __restrict__ mean,
+                                                               float* __restrict__ rstd, float* running_mean, float* running_var,
+                                                               float momentum) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= G * C) return;
-    int g = i / C, c = i - g * C;
+    const int c = i % C;
     double s = 0, q = 0;
-    for (int k = 0; k < chunks; ++k) {
-        const double* o = part + ((int64_t)(g * chunks + k) * C + c) * 2;
-        s += o[0];
-        q += o[1];
-    }
+    const double* o = part + (int64_t)i * chunks * 2;
+    for (int k = lane; k < chunks; k += 64) { s += o[k * 2]; q += o[k * 2 + 1]; }
+    wave_sum2(s, q);
+    if (lane != 0) return;
     double m = s / (double)rows_per_group;
     double var = q / (double)rows_per_group - m * m;
     if (var < 0) var = 0;
@@ -118,22 +127,22 @@ __global__ void norm_stats_final_kernel(const double* __restrict__ part, int chu
     }
 }
 
-// sums[(g*C + c)*2 + {0,1}] = (sum g, sum g*xhat) ; optional dgamma/dbeta
-__global__ void norm_bwd_final_kernel(const double* __restrict__ part, int chunks, int G, int C, float* __restrict__ sums,
-                                      float* dgamma, float* dbeta) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+// sums[(g*C + c)*2 + {0,1}] = (sum g, sum g*xhat) ; optional dgamma/dbeta ; colsum (bias gradient)
+__global__ __launch_bounds__(256) void norm_bwd_final_kernel(const double* __restrict__ part, int chunks, int G, int C,
+                                                             float* __restrict__ sums, float* dgamma, float* dbeta, float* colsum) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= G * C) return;
-    int g = i / C, c = i - g * C;
+    const int c = i % C;
     double s = 0, q = 0;
-    for (int k = 0; k < chunks; ++k) {
-        const double* o = part + ((int64_t)(g * chunks + k) * C + c) * 2;
-        s += o[0];
-        q += o[1];
-    }
-    sums[i * 2] = (float)s;
-    sums[i * 2 + 1] = (float)q;
+    const double* o = part + (int64_t)i * chunks * 2;
+    for (int k = lane; k < chunks; k += 64) { s += o[k * 2]; q += o[k * 2 + 1]; }
+    wave_sum2(s, q);
+    if (lane != 0) return;
+    if (sums) { sums[i * 2] = (float)s; sums[i * 2 + 1] = (float)q; }
     if (dgamma) dgamma[c] = (float)q;
     if (dbeta) dbeta[c] = (float)s;
+    if (colsum) colsum[c] = (float)s;
 }
 
 __global__ void eval_rstd_kernel(const float* __restrict__ var, float eps, float* __restrict__ rstd, int C) {
@@ -269,7 +278,7 @@ extern "C" int corrif_norm_stats(const float* x, int64_t ldx, int64_t rows_per_g
                        (const float*)nullptr, (int64_t)0, (const float*)nullptr, (const float*)nullptr, ws, rows_per_group, (int)C,
                        (int)flags, n);
     CORRIF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(norm_stats_final_kernel, dim3((G * C + 255) / 256), dim3(256), 0, s, (const double*)ws, n.chunks, (int)G, (int)C,
+    hipLaunchKernelGGL(norm_stats_final_kernel, dim3((G * C + 3) / 4), dim3(256), 0, s, (const double*)ws, n.chunks, (int)G, (int)C,
                        rows_per_group, eps, mean, rstd, running_mean, running_var, momentum);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
@@ -317,8 +326,8 @@ extern "C" int corrif_norm_bwd(const float* dy, int64_t lddy, const float* y, in
         hipLaunchKernelGGL((norm_partial_kernel<1>), dim3(n.chunks, n.ctiles, G), dim3(256), 0, s, x, ldx, dy, lddy, y, ldy, mean, rstd, ws,
                            rows_per_group, (int)C, (int)flags, n);
         CORRIF_CHECK_LAUNCH();
-        hipLaunchKernelGGL(norm_bwd_final_kernel, dim3((G * C + 255) / 256), dim3(256), 0, s, (const double*)ws, n.chunks, (int)G, (int)C,
-                           sums, dgamma, dbeta);
+        hipLaunchKernelGGL(norm_bwd_final_kernel, dim3((G * C + 3) / 4), dim3(256), 0, s, (const double*)ws, n.chunks, (int)G, (int)C,
+                           sums, dgamma, dbeta, (float*)nullptr);
         CORRIF_CHECK_LAUNCH();
     }
     if (dx || dres) {
@@ -328,6 +337,22 @@ extern "C" int corrif_norm_bwd(const float* dy, int64_t lddy, const float* y, in
                            (const float*)sums, dx, lddx, dres, lddres, rows_per_group, (int)C, (int)flags, (int)frozen, a);
         CORRIF_CHECK_LAUNCH();
     }
+    return CORRIF_OK;
+}
+
+// column sums (bias gradients): the statistics partial pass (sum, sum^2) + the wave-per-channel final
+extern "C" size_t corrif_col_sum_workspace(int64_t rows, int32_t C) { return corrif_norm_workspace(rows, 1, C); }
+extern "C" int corrif_col_sum(const float* x, int64_t ld, int64_t rows, int32_t C, float* out, double* ws, void* stream) {
+    if (!x || !out || !ws || !norm_args_ok(rows, 1, C)) return CORRIF_EINVAL;
+    if ((ld & 3) || !al16(x)) return CORRIF_EUNSUPPORTED;
+    NormGeo n = norm_geo(rows, 1, C);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((norm_partial_kernel<0>), dim3(n.chunks, n.ctiles, 1), dim3(256), 0, s, x, ld, (const float*)nullptr, (int64_t)0,
+                       (const float*)nullptr, (int64_t)0, (const float*)nullptr, (const float*)nullptr, ws, rows, (int)C, 0, n);
+    CORRIF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(norm_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, s, (const double*)ws, n.chunks, 1, (int)C, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, out);
+    CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
 

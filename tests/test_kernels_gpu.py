@@ -51,6 +51,9 @@ CONVS = [
     ("3x3x3_zero", 24, 24, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, (2, 4, 9, 10), True),
     ("3x3x3_rep_small_n", 32, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (2, 8, 8, 8), True),
     ("3x3x3_rep_320", 320, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (1, 6, 6, 6), True),
+    ("3x3x3_rep_16_8", 16, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (2, 9, 8, 10), True),
+    ("3x3x3_zero_16_16", 16, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, (1, 7, 9, 8), True),
+    ("1x1_12_to_4", 12, 4, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 5, 6, 7), True),
     ("1x1_n8", 8, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 6, 6, 6), True),
     ("1x1_wide", 2048, 192, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (1, 4, 4, 4), True),
 ]
