@@ -37,8 +37,8 @@ class MfmaTimer:
 
     def __init__(self, ops):
         self.ops, self.rec, self.on = ops, [], False
-        self._gemm, self._wgrad = ops.gemm, ops.wgrad
-        ops.gemm, ops.wgrad = self.gemm, self.wgrad
+        self._gemm, self._wgrad, self._patch = ops.gemm, ops.wgrad, ops.conv3_patch
+        ops.gemm, ops.wgrad, ops.conv3_patch = self.gemm, self.wgrad, self.patch
 
     def _timed(self, fn, flops, key, a, kw):
         if not self.on:
@@ -57,6 +57,11 @@ class MfmaTimer:
     def wgrad(self, *a, **kw):      # (A, lda, B, ldb, Cs, C, ldc, R, M, N, geom, ...)
         key = ("wgrad", a[7], a[8], a[9], kw.get("Z", 1))
         return self._timed(self._wgrad, 2.0 * a[7] * a[8] * a[9] * kw.get("Z", 1), key, a, kw)
+
+    def patch(self, *a, **kw):      # (x, ldx, wp, y, ldy, bias, B, S, O, Ci, Co, pad, clamp, cc)
+        M = a[6] * a[8][0] * a[8][1] * a[8][2]
+        key = ("patch_dgrad" if a[11] == 2 or a[5] == 0 else "patch_conv", M, a[10], 27 * a[9], 1)
+        return self._timed(self._patch, 2.0 * M * a[10] * 27 * a[9], key, a, kw)
 
     def by_shape(self):
         agg = {}
@@ -187,7 +192,7 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                               "kernel": "gemm_fwd_kernel+wgrad_kernel (fp32 MFMA implicit GEMM)", "launches_per_step": n // args.steps,
+                               "kernel": "gemm_fwd_kernel+wgrad_kernel+conv3_patch_kernel (fp32 MFMA implicit GEMM / patch conv)", "launches_per_step": n // args.steps,
                                "mfma_ms_per_step": round(ms / args.steps, 3),
                                "algorithmic_gflop_per_step": round(fl / args.steps / 1e9, 1),
                                "whole_step_frac": round(FLOP_PER_IMAGE_FWD_BWD * B / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}

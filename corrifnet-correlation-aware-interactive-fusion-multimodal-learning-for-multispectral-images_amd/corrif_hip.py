@@ -39,6 +39,12 @@ class Wgrad(C.Structure):
                 ("sA_o", i64), ("sA_i", i64), ("sB_o", i64), ("sB_i", i64), ("sC_o", i64), ("sC_i", i64), ("g", Geom)]
 
 
+class Conv3Patch(C.Structure):
+    _fields_ = [("X", ptr), ("ldx", i64), ("Wp", ptr), ("Y", ptr), ("ldy", i64), ("bias", ptr),
+                ("B", i32), ("Sd", i32), ("Sh", i32), ("Sw", i32), ("Od", i32), ("Oh", i32), ("Ow", i32),
+                ("Ci", i32), ("Co", i32), ("pad", i32), ("clamp", i32), ("cc", i32)]
+
+
 _SIGS = {
     "corrif_abi_version": (i32, []),
     "corrif_build_arch": (C.c_char_p, []),
@@ -46,6 +52,8 @@ _SIGS = {
     "corrif_wgrad": (i32, [C.POINTER(Wgrad), ptr]),
     "corrif_wgrad_workspace": (C.c_size_t, [C.POINTER(Wgrad)]),
     "corrif_wgrad_plan": (i32, [i32, i32, i32]),
+    "corrif_conv3_patch": (i32, [C.POINTER(Conv3Patch), ptr]),
+    "corrif_conv3_patch_cc": (i32, [i32, i32]),
     "corrif_slab_reduce": (i32, [ptr, ptr, i64, i32, ptr]),
     "corrif_col_sum": (i32, [ptr, i64, i64, i32, ptr, ptr, ptr]),
     "corrif_col_sum_workspace": (C.c_size_t, [i64, i32]),

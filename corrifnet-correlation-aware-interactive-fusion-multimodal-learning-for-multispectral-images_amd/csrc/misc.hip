@@ -124,17 +124,33 @@ __global__ void repack_kernel(const float* __restrict__ in, float* __restrict__ 
             int64_t r = e / I;
             int o = (int)(r % O), t = (int)(r / O);
             out[e] = in[((int64_t)o * I + i) * T + t];
-        } else {                  // w[o][i][t] = in[o][t][i] (row pitch ldo)
+        } else if (mode == 2) {   // w[o][i][t] = in[o][t][i] (row pitch ldo)
             int t = (int)(e % T);
             int64_t r = e / T;
             int i = (int)(r % I), o = (int)(r / I);
             out[e] = in[(int64_t)o * ldo + (int64_t)t * I + i];
+        } else if (mode == 3) {   // out[ch][o][t][c] = w[o][ch*cc + c][t]
+            const int cc = (int)ldo;
+            int c = (int)(e % cc);
+            int64_t r = e / cc;
+            int t = (int)(r % T); r /= T;
+            int o = (int)(r % O), ch = (int)(r / O);
+            out[e] = in[((int64_t)o * I + ch * cc + c) * T + t];
+        } else {                  // out[ch][i][t'][c] = w[ch*cc + c][i][T-1-t']
+            const int cc = (int)ldo;
+            int c = (int)(e % cc);
+            int64_t r = e / cc;
+            int t = (int)(r % T); r /= T;
+            int i = (int)(r % I), ch = (int)(r / I);
+            out[e] = in[((int64_t)(ch * cc + c) * I + i) * T + (T - 1 - t)];
         }
     }
 }
 extern "C" int corrif_weight_repack(const float* in, float* out, int32_t O, int32_t I, int32_t T, int32_t mode, int64_t ldo, void* stream) {
-    if (!in || !out || O <= 0 || I <= 0 || T <= 0 || mode < 0 || mode > 2) return CORRIF_EINVAL;
-    if (mode != 1 && ldo < (int64_t)I * T) return CORRIF_EINVAL;
+    if (!in || !out || O <= 0 || I <= 0 || T <= 0 || mode < 0 || mode > 4) return CORRIF_EINVAL;
+    if ((mode == 0 || mode == 2) && ldo < (int64_t)I * T) return CORRIF_EINVAL;
+    if (mode == 3 && (ldo <= 0 || I % ldo)) return CORRIF_EINVAL;
+    if (mode == 4 && (ldo <= 0 || O % ldo)) return CORRIF_EINVAL;
     hipLaunchKernelGGL(repack_kernel, dim3(nblocks((int64_t)O * I * T)), dim3(256), 0, (hipStream_t)stream, in, out, (int)O, (int)I, (int)T,
                        (int)mode, ldo);
     CORRIF_CHECK_LAUNCH();

@@ -104,6 +104,24 @@ def repack(src, shape_out, O, I, T, mode, ldo, zero=False):
     return out
 
 
+def conv3_patch(x, ldx, wp, y, ldy, bias, B, S, O, Ci, Co, pad, clamp, cc):
+    q = H.Conv3Patch()
+    q.X, q.ldx, q.Wp, q.Y, q.ldy = x, ldx, wp, y, ldy
+    q.bias = bias
+    q.B = B
+    q.Sd, q.Sh, q.Sw = S
+    q.Od, q.Oh, q.Ow = O
+    q.Ci, q.Co, q.pad, q.clamp, q.cc = Ci, Co, pad, 1 if clamp else 0, cc
+    check(lib().corrif_conv3_patch(q, stream()), "corrif_conv3_patch")
+
+
+def _patch_cc(k, stride, pad, Ci, Co):
+    """channel chunk of the patch-staged 3x3x3 kernel for this layer, 0 = use the implicit GEMM"""
+    if k != (3, 3, 3) or stride != (1, 1, 1) or pad != (1, 1, 1):
+        return 0
+    return lib().corrif_conv3_patch_cc(Ci, Co)
+
+
 def _out_size(i, k, s, p):
     return (i + 2 * p - k) // s + 1
 
@@ -138,6 +156,10 @@ class ConvFn(Function):
             wp = repack(weight, (Co, Kp), Co, 1, T, 0, Kp, zero=True)
             geom = H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad, ntaps=T, src_batch_pitch=batch_pitch)
             gemm(P(x), 1, P(wp), Kp, 0, P(y), ldc, M, Co, Kp, 1, geom, bias=P(bias) if bias is not None else None, act=act)
+        elif _patch_cc((kd, kh, kw), stride, pad, Ci, Co) and act == ACT_NONE:
+            cc = _patch_cc((kd, kh, kw), stride, pad, Ci, Co)
+            wp = repack(weight, (Ci // cc, Co, T, cc), Co, Ci, T, 3, cc)
+            conv3_patch(P(x), lda, P(wp), P(y), ldc, P(bias), B, (Di, Hi, Wi), (Do, Ho, Wo), Ci, Co, 1, replicate, cc)
         else:
             wp = weight if T == 1 else repack(weight, (Co, T * Ci), Co, Ci, T, 0, T * Ci)
             geom = H.gemm_geom() if is_gemm else H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad, clamp=replicate)
@@ -160,6 +182,16 @@ class ConvFn(Function):
             Min = B * Di * Hi * Wi
             if is_gemm:        # dX[M,Ci] = dY[M,Co] . W[Co,Ci]   (W is the [K][N] operand as stored)
                 gemm(P(gy), ldg, P(weight), Ci, 1, P(gx), Ci, Min, Ci, Co, Co, H.gemm_geom())
+            elif _patch_cc((kd, kh, kw), stride, pad, Co, Ci):      # data gradient = patch conv of dY with flipped weights
+                cc = _patch_cc((kd, kh, kw), stride, pad, Co, Ci)
+                wd = repack(weight, (Co // cc, Ci, T, cc), Co, Ci, T, 4, cc)
+                if replicate:
+                    Rg = (Di + 2, Hi + 2, Wi + 2)
+                    gxp = torch.empty((B,) + Rg + (Ci,), dtype=torch.float32, device=dev)
+                    conv3_patch(P(gy), ldg, P(wd), P(gxp), Ci, 0, B, (Do, Ho, Wo), Rg, Co, Ci, 2, False, cc)
+                    check(lib().corrif_pad_fold(P(gxp), P(gx), Ci, B, Di, Hi, Wi, Ci, stream()), "corrif_pad_fold")
+                else:
+                    conv3_patch(P(gy), ldg, P(wd), P(gx), Ci, 0, B, (Do, Ho, Wo), (Di, Hi, Wi), Co, Ci, 1, False, cc)
             else:
                 wd = weight if T == 1 else repack(weight, (T * Co, Ci), Co, Ci, T, 1, T * Ci)
                 if replicate:  # gradient on the replicate-padded grid, then fold the halo back (adjoint of the clamp)

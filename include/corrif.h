@@ -113,9 +113,29 @@ size_t corrif_col_sum_workspace(int64_t rows, int32_t C);
 /* weight re-layouts (private caches of the host layer; reference layout is O,I,kd,kh,kw):
  *   mode 0: out[o][t][i] = w[o][i][t]   (forward / weight-gradient layout, [N][K])
  *   mode 1: out[t][o][i] = w[o][i][t]   (data-gradient layout, [K][N], taps NOT flipped: dir=-1)
- *   mode 2: w[o][i][t] = in[o][t][i]    (weight-gradient back to the reference layout)          */
+ *   mode 2: w[o][i][t] = in[o][t][i]    (weight-gradient back to the reference layout)
+ *   mode 3: out[ch][o][t][c] = w[o][ch*cc + c][t]           (patch kernel, forward;  ldo carries cc)
+ *   mode 4: out[ch][i][t'][c] = w[ch*cc + c][i][T-1-t']     (patch kernel, data gradient; ldo carries cc) */
 int corrif_weight_repack(const float* in, float* out, int32_t O, int32_t I, int32_t T, int32_t mode, int64_t ldo, void* stream);
 /* ldo: row pitch (floats, >= T*I) of the [o][t][i] side in modes 0 and 2 (the stem pads 147 -> 148) */
+
+/* Patch-staged direct 3x3x3 convolution (stride 1) for narrow layers, Cout <= 32, Cin % 8 == 0: the decoder's
+ * d*_c1 / d*_c2 and RFM 3x3x3 convs (mmvit4.py:52,225-235) and their data gradients.  The workgroup stages the halo'd input
+ * patch of a 256-voxel output tile in LDS once per channel chunk; taps are LDS reads; v_mfma_f32_4x4x1_16b_f32 with A-operand
+ * broadcast.  out[o] = bias + sum_t W[t] . X[clamp|zero(o + t - pad)],  o in the Od x Oh x Ow grid.
+ *   forward      : pad = 1, (Od,Oh,Ow) = (Sd,Sh,Sw), clamp = replicate?   weights from corrif_weight_repack mode 3
+ *   data gradient: X = dY, weights mode 4 (flipped taps, transposed channels); zero padding: pad = 1 same grid;
+ *                  replicate padding: pad = 2 on the (S+2)^3 grid, then corrif_pad_fold.
+ * cc must equal corrif_conv3_patch_cc(Ci, Co) (channel chunk, 16 or 8; 0 = shape not supported). */
+typedef struct CorrifConv3Patch {
+    const float* X; int64_t ldx;
+    const float* Wp;                 /* [Ci/cc][Co][27][cc] */
+    float* Y; int64_t ldy;
+    const float* bias;               /* [Co] or NULL */
+    int32_t B, Sd, Sh, Sw, Od, Oh, Ow, Ci, Co, pad, clamp, cc;
+} CorrifConv3Patch;
+int corrif_conv3_patch(const CorrifConv3Patch* p, void* stream);
+int corrif_conv3_patch_cc(int32_t Ci, int32_t Co);     /* host-only */
 
 /* Stem: Conv3d(1->64,(3,7,7),stride (1,2,2),pad (1,3,3), no bias) on x[:, m] of the NCDHW input
  * (mmvit4.py:120,172; aten::convolution with Cin = 1) runs through corrif_gemm_fwd / corrif_wgrad

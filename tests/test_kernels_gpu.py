@@ -53,6 +53,10 @@ CONVS = [
     ("3x3x3_rep_320", 320, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (1, 6, 6, 6), True),
     ("3x3x3_rep_16_8", 16, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (2, 9, 8, 10), True),
     ("3x3x3_zero_16_16", 16, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, (1, 7, 9, 8), True),
+    ("3x3x3_rep_64_32", 64, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (1, 5, 6, 18), True),
+    ("3x3x3_zero_d1", 16, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, (2, 1, 9, 20), True),
+    ("3x3x3_rep_d2", 8, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (2, 2, 17, 33), False),
+    ("3x3x3_zero_48", 48, 48, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, (1, 4, 10, 10), True),
     ("1x1_12_to_4", 12, 4, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 5, 6, 7), True),
     ("1x1_n8", 8, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 6, 6, 6), True),
     ("1x1_wide", 2048, 192, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (1, 4, 4, 4), True),
