@@ -37,8 +37,8 @@ class MfmaTimer:
 
     def __init__(self, ops):
         self.ops, self.rec, self.on = ops, [], False
-        self._gemm, self._wgrad, self._patch = ops.gemm, ops.wgrad, ops.conv3_patch
-        ops.gemm, ops.wgrad, ops.conv3_patch = self.gemm, self.wgrad, self.patch
+        self._gemm, self._wgrad, self._patch, self._pwg = ops.gemm, ops.wgrad, ops.conv3_patch, ops.conv3_patch_wgrad
+        ops.gemm, ops.wgrad, ops.conv3_patch, ops.conv3_patch_wgrad = self.gemm, self.wgrad, self.patch, self.patch_wgrad
 
     def _timed(self, fn, flops, key, a, kw):
         if not self.on:
@@ -62,6 +62,10 @@ class MfmaTimer:
         M = a[6] * a[8][0] * a[8][1] * a[8][2]
         key = ("patch_dgrad" if a[11] == 2 or a[5] == 0 else "patch_conv", M, a[10], 27 * a[9], 1)
         return self._timed(self._patch, 2.0 * M * a[10] * 27 * a[9], key, a, kw)
+
+    def patch_wgrad(self, *a, **kw):   # (x, ldx, gy, ldg, gwp, B, S, O, Ci, Co, clamp, dev)
+        M = a[5] * a[7][0] * a[7][1] * a[7][2]
+        return self._timed(self._pwg, 2.0 * M * a[9] * 27 * a[8], ("patch_wgrad", M, a[9], 27 * a[8], 1), a, kw)
 
     def by_shape(self):
         agg = {}

@@ -45,6 +45,12 @@ class Conv3Patch(C.Structure):
                 ("Ci", i32), ("Co", i32), ("pad", i32), ("clamp", i32), ("cc", i32)]
 
 
+class Conv3PatchWgrad(C.Structure):
+    _fields_ = [("X", ptr), ("ldx", i64), ("DY", ptr), ("lddy", i64), ("dW", ptr), ("ws", ptr),
+                ("B", i32), ("Sd", i32), ("Sh", i32), ("Sw", i32), ("Od", i32), ("Oh", i32), ("Ow", i32),
+                ("Ci", i32), ("Co", i32), ("pad", i32), ("clamp", i32)]
+
+
 _SIGS = {
     "corrif_abi_version": (i32, []),
     "corrif_build_arch": (C.c_char_p, []),
@@ -54,6 +60,9 @@ _SIGS = {
     "corrif_wgrad_plan": (i32, [i32, i32, i32]),
     "corrif_conv3_patch": (i32, [C.POINTER(Conv3Patch), ptr]),
     "corrif_conv3_patch_cc": (i32, [i32, i32]),
+    "corrif_conv3_patch_wgrad": (i32, [C.POINTER(Conv3PatchWgrad), ptr]),
+    "corrif_conv3_patch_wgrad_workspace": (C.c_size_t, [i32, i32]),
+    "corrif_conv3_patch_wgrad_slots": (i32, [i32, i32]),
     "corrif_slab_reduce": (i32, [ptr, ptr, i64, i32, ptr]),
     "corrif_col_sum": (i32, [ptr, i64, i64, i32, ptr, ptr, ptr]),
     "corrif_col_sum_workspace": (C.c_size_t, [i64, i32]),

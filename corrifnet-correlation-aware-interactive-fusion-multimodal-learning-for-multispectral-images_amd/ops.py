@@ -115,6 +115,17 @@ def conv3_patch(x, ldx, wp, y, ldy, bias, B, S, O, Ci, Co, pad, clamp, cc):
     check(lib().corrif_conv3_patch(q, stream()), "corrif_conv3_patch")
 
 
+def conv3_patch_wgrad(x, ldx, gy, ldg, gwp, B, S, O, Ci, Co, clamp, dev):
+    q = H.Conv3PatchWgrad()
+    ws = _ws(lib().corrif_conv3_patch_wgrad_workspace(Ci, Co), dev)
+    q.X, q.ldx, q.DY, q.lddy, q.dW, q.ws = x, ldx, gy, ldg, gwp, ws.data_ptr()
+    q.B = B
+    q.Sd, q.Sh, q.Sw = S
+    q.Od, q.Oh, q.Ow = O
+    q.Ci, q.Co, q.pad, q.clamp = Ci, Co, 1, 1 if clamp else 0
+    check(lib().corrif_conv3_patch_wgrad(q, stream()), "corrif_conv3_patch_wgrad")
+
+
 def _patch_cc(k, stride, pad, Ci, Co):
     """channel chunk of the patch-staged 3x3x3 kernel for this layer, 0 = use the implicit GEMM"""
     if k != (3, 3, 3) or stride != (1, 1, 1) or pad != (1, 1, 1):
@@ -217,8 +228,11 @@ class ConvFn(Function):
                 wgrad(P(gy), ldg, P(x), lda, Ci, P(gw), Ci, M, Co, Ci, geom, dev)
             else:
                 gwp = torch.empty((Co, T * Ci), dtype=torch.float32, device=dev)
-                geom = H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad, clamp=replicate)
-                wgrad(P(gy), ldg, P(x), lda, Ci, P(gwp), T * Ci, M, Co, T * Ci, geom, dev)
+                if (kd, kh, kw) == (3, 3, 3) and stride == (1, 1, 1) and pad == (1, 1, 1) and lib().corrif_conv3_patch_wgrad_slots(Ci, Co):
+                    conv3_patch_wgrad(P(x), lda, P(gy), ldg, P(gwp), B, (Di, Hi, Wi), (Do, Ho, Wo), Ci, Co, replicate, dev)
+                else:
+                    geom = H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad, clamp=replicate)
+                    wgrad(P(gy), ldg, P(x), lda, Ci, P(gwp), T * Ci, M, Co, T * Ci, geom, dev)
                 gw = repack(gwp, weight.shape, Co, Ci, T, 2, T * Ci)
         if has_bias and ctx.needs_input_grad[2]:
             gb = col_sum(gy, M, ldg, Co)

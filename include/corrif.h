@@ -136,6 +136,17 @@ typedef struct CorrifConv3Patch {
 } CorrifConv3Patch;
 int corrif_conv3_patch(const CorrifConv3Patch* p, void* stream);
 int corrif_conv3_patch_cc(int32_t Ci, int32_t Co);     /* host-only */
+/* weight gradient of the same layers (Cout <= 16, Cin % 16 == 0): dW[Co][27][Ci] (then corrif_weight_repack mode 2).
+ * X is the layer input (S grid), DY the output gradient (O grid = S grid, pad 1), ws = corrif_conv3_patch_wgrad_workspace bytes. */
+typedef struct CorrifConv3PatchWgrad {
+    const float* X; int64_t ldx;
+    const float* DY; int64_t lddy;
+    float* dW; float* ws;
+    int32_t B, Sd, Sh, Sw, Od, Oh, Ow, Ci, Co, pad, clamp;
+} CorrifConv3PatchWgrad;
+int corrif_conv3_patch_wgrad(const CorrifConv3PatchWgrad* p, void* stream);
+size_t corrif_conv3_patch_wgrad_workspace(int32_t Ci, int32_t Co);   /* host-only; 0 = shape not supported */
+int corrif_conv3_patch_wgrad_slots(int32_t Ci, int32_t Co);          /* host-only */
 
 /* Stem: Conv3d(1->64,(3,7,7),stride (1,2,2),pad (1,3,3), no bias) on x[:, m] of the NCDHW input
  * (mmvit4.py:120,172; aten::convolution with Cin = 1) runs through corrif_gemm_fwd / corrif_wgrad
