@@ -347,6 +347,23 @@ class MMVit4(nn.Module):
         self.decoder_fuse = Decoder_fuse(num_cls=num_cls)
         for i, c in enumerate((basic_dims, basic_dims * 2, basic_dims * 4, d8, d8, d8)):
             setattr(self, "fusion%d" % (i + 1), EarlyFusionBlock(c))
+        # The three modality branches (encoder -> tokens -> intra-modality transformer -> qkv) are independent until the
+        # inter-modal correlation: run them on three HIP streams so that their small late-stage launches (e4/e5: 1-2
+        # workgroups per CU each) fill the 256 CUs together.  Same kernels, same order per branch: results are unchanged.
+        self.concurrent_branches = True
+        self._streams = None
+
+    @staticmethod
+    def _level_shapes(B, D, H, W):
+        def o(v, k, s, p):
+            return (v + 2 * p - k) // s + 1
+        h, w = o(o(H, 7, 2, 3), 3, 2, 1), o(o(W, 7, 2, 3), 3, 2, 1)
+        shapes = [(B, D, h, w)]
+        shapes.append((B, D, h, w))
+        for _ in range(3):
+            h, w = o(h, 3, 2, 1), o(w, 3, 2, 1)
+            shapes.append((B, D, h, w))
+        return shapes
 
     def forward(self, x):
         if not x.is_cuda:
@@ -355,17 +372,38 @@ class MMVit4(nn.Module):
             raise ValueError("expected fp32 input [B, 3, D, H, W]")
         B = x.shape[0]
         P3, T = patch_size, transformer_basic_dims
-        cats = [None] * 6
-        feats = [getattr(self, m + "_encoder")(x[:, i], i, cats) for i, m in enumerate(_MODS)]
+        # early-fusion concat buffers, allocated up front on the caller's stream (the branches fill their channel slices)
+        cats = [torch.empty(sh + (num_modals * c,), dtype=torch.float32, device=x.device)
+                for sh, (_, c) in zip(self._level_shapes(B, x.shape[2], x.shape[3], x.shape[4]), _ADAPT)]
+        cats.append(torch.empty((B, P3, P3, P3, num_modals * basic_dims * 8), dtype=torch.float32, device=x.device))
+        feats, skip, qkv = [None] * 3, [None] * 3, [None] * 3
+
+        def branch(i, m):
+            feats[i] = getattr(self, m + "_encoder")(x[:, i], i, cats)
+            tok = getattr(self, m + "_encode_conv")(feats[i][5]).view(B, P3 ** 3, T)       # channels-last == token layout (:458-461)
+            skip[i] = tok
+            tr = getattr(self, m + "_transformer")(tok, getattr(self, m + "_pos"))
+            qkv[i] = getattr(self, "qkv_" + m)(tr.view(B, P3, P3, P3, T)).view(B, P3 ** 3, 3 * T)
+
+        if self.concurrent_branches:
+            cur = torch.cuda.current_stream()
+            if self._streams is None:
+                self._streams = [torch.cuda.Stream(device=x.device) for _ in range(num_modals)]
+            for i, m in enumerate(_MODS):
+                st = self._streams[i]
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    branch(i, m)
+            for st in self._streams:
+                cur.wait_stream(st)
+            for i in range(num_modals):        # branch outputs are consumed on the caller's stream from here on
+                for t in feats[i] + [skip[i], qkv[i]]:
+                    t.record_stream(cur)
+        else:
+            for i, m in enumerate(_MODS):
+                branch(i, m)
         fused = [getattr(self, "fusion%d" % (l + 1))(ops.cat_channels(cats[l], *[feats[i][l] for i in range(num_modals)]))
                  for l in range(6)]            # fused[4] (fusion5) is computed and never consumed, as in the reference (:453)
-
-        skip, trans = [], []
-        for i, m in enumerate(_MODS):
-            tok = getattr(self, m + "_encode_conv")(feats[i][5]).view(B, P3 ** 3, T)       # channels-last == token layout (:458-461)
-            skip.append(tok)
-            trans.append(getattr(self, m + "_transformer")(tok, getattr(self, m + "_pos")))
-        qkv = [getattr(self, "qkv_" + m)(trans[i].view(B, P3, P3, P3, T)).view(B, P3 ** 3, 3 * T) for i, m in enumerate(_MODS)]
         corr = ops.inter_corr(qkv[0], qkv[1], qkv[2])                                      # mmvit4.py:481-503
         mm = [ops.add(skip[i], corr[i]) for i in range(num_modals)]
         mm.append(self.fused6_encode_conv(fused[5]).view(B, P3 ** 3, T))

@@ -129,7 +129,7 @@ def test_full_gradient_against_oracle():
         lr.backward()
         res[dt] = (pr.detach().double(), lr.item(), {k: (None if p.grad is None else p.grad.double()) for k, p in ref.named_parameters()},
                    {k: b.double() for k, b in ref.named_buffers()})
-    p32, l32, g32, _ = res[torch.float32]
+    p32, l32, g32, b32 = res[torch.float32]
     p64, l64, g64, b64 = res[torch.float64]
     gap = (p32 - p64).abs().max().item()
     assert (pred.detach().cpu().double() - p64).abs().max().item() < max(3 * gap, 2e-5)
@@ -145,8 +145,13 @@ def test_full_gradient_against_oracle():
         if e_hip > max(3 * e_ref, 2e-4):
             bad.append((k, e_hip, e_ref))
     assert not bad, bad[:10]
-    for k, b in model.named_buffers():                # running statistics after one training step
-        assert torch.allclose(b.cpu().double(), b64[k], rtol=1e-3, atol=1e-5), k
+    for k, b in model.named_buffers():                # running statistics after one training step, bracketed the same way
+        if k.endswith("num_batches_tracked"):         # (e5 sees 1x1 maps here: statistics over 3 samples per channel)
+            assert int(b) == int(b64[k]), k
+            continue
+        err = (b.cpu().double() - b64[k]).abs()
+        bound = torch.maximum(3 * (b32[k] - b64[k]).abs(), 1e-5 + 1e-3 * b64[k].abs())
+        assert bool((err <= bound).all()), (k, err.max().item())
 
 
 def test_module_surface():
