@@ -8,9 +8,11 @@ One JSON line on rank 0.  metric = images/s for one forward + backward of MMVit4
 inputs resident in HBM, random-init weights.  N > 1: weak scaling, one replica per GPU on its own 32-image shard, gradients
 averaged with bucketed RCCL all-reduce (inside the timed region).
 
-roofline: the dominant kernel family is the fp32 MFMA implicit-GEMM (`gemm_fwd_kernel` / `wgrad_kernel`); `achieved` is the
-algorithmic FLOPs of those launches (2*M*N*K each, from the launch descriptors) divided by their summed duration measured
-with HIP events on the launch stream inside the timed region; peak = 157.3 TFLOP/s (fp32 matrix, MI355X_MICROARCH.md).
+roofline: the dominant kernel family is the fp32 MFMA implicit-GEMM / patch-conv family; `achieved` is the algorithmic FLOPs
+of those launches (2*M*N*K each, from the launch descriptors) divided by their summed duration measured with HIP events
+around every launch, in extra steps right after the timed region with the three modality branches serialised (the timed
+region itself runs them on three concurrent streams, where an event pair would also span other streams' kernels);
+`whole_step_frac` prices the WHOLE timed step (645.9 GFLOP/image) against the same peak = 157.3 TFLOP/s (fp32 matrix).
 cpu_baseline: the CPU oracle (stock-PyTorch restatement, bit-identical to the reference on CPU) timed on the host cores.
 """
 import argparse
@@ -93,7 +95,9 @@ def cpu_baseline(B=2, D=4, HW=224, iters=2):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = max(1, min(cores, int(os.environ.get("CORRIF_CPU_THREADS", "16"))))   # a 1-GPU box owns a 16-core CPU share
     torch.set_num_threads(cores)
+    print("[bench] timing the CPU oracle on %d host threads (B=%d, about %d fwd+bwd steps) ..." % (cores, B, iters + 1), file=sys.stderr, flush=True)
     torch.manual_seed(0)
     m = O.MMVit4().train()
     x, mask = helpers.make_inputs(B, D, HW, HW)
@@ -103,6 +107,7 @@ def cpu_baseline(B=2, D=4, HW=224, iters=2):
         m.zero_grad(set_to_none=True)
         O.train_step_loss(m(x), mask).backward()
         ts.append(time.time() - t0)
+        print("[bench]   cpu step %d: %.1f s" % (i, ts[-1]), file=sys.stderr, flush=True)
     best = min(ts[1:])
     return {"value": round(B / best, 4), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": "oracle (CPU restatement of mmvit4.MMVit4, bit-identical to the reference on CPU) fwd+loss+bwd, "
@@ -164,8 +169,6 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    if timer:
-        timer.on = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -174,8 +177,19 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if timer:
+    kt_steps = 0
+    if timer and rank == 0:
+        # per-launch durations of the MFMA kernels: HIP events around every launch, in an extra pass right after the timed
+        # region with the three modality branches serialised on one stream (with concurrent streams an event pair also
+        # spans the other streams' kernels, so per-kernel durations are only meaningful one stream at a time)
+        model.concurrent_branches = False
+        kt_steps = min(2, args.steps)
+        timer.on = True
+        for _ in range(kt_steps):
+            step()
+        torch.cuda.synchronize()
         timer.on = False
+        model.concurrent_branches = True
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -196,9 +210,10 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                               "kernel": "gemm_fwd_kernel+wgrad_kernel+conv3_patch_kernel (fp32 MFMA implicit GEMM / patch conv)", "launches_per_step": n // args.steps,
-                               "mfma_ms_per_step": round(ms / args.steps, 3),
-                               "algorithmic_gflop_per_step": round(fl / args.steps / 1e9, 1),
+                               "kernel": "gemm_fwd_kernel+wgrad_kernel+conv3_patch_kernel (fp32 MFMA implicit GEMM / patch conv)",
+                               "launches_per_step": n // max(kt_steps, 1), "mfma_ms_per_step": round(ms / max(kt_steps, 1), 3),
+                               "algorithmic_gflop_per_step": round(fl / max(kt_steps, 1) / 1e9, 1),
+                               "method": "HIP events around each MFMA launch, %d extra single-stream steps after the timed region" % kt_steps,
                                "whole_step_frac": round(FLOP_PER_IMAGE_FWD_BWD * B / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
         if timer and args.dump_shapes:
             with open(args.dump_shapes, "w") as f:

@@ -149,9 +149,10 @@ def test_full_gradient_against_oracle():
         if k.endswith("num_batches_tracked"):         # (e5 sees 1x1 maps here: statistics over 3 samples per channel)
             assert int(b) == int(b64[k]), k
             continue
-        err = (b.cpu().double() - b64[k]).abs()
-        bound = torch.maximum(3 * (b32[k] - b64[k]).abs(), 1e-5 + 1e-3 * b64[k].abs())
-        assert bool((err <= bound).all()), (k, err.max().item())
+        nrm = b64[k].norm().clamp_min(1e-20)             # per-tensor rel-L2 (single elements are chaotic with 3 samples/channel)
+        e_hip = ((b.cpu().double() - b64[k]).norm() / nrm).item()
+        e_ref = ((b32[k] - b64[k]).norm() / nrm).item()
+        assert e_hip <= max(3 * e_ref, 1e-4), (k, e_hip, e_ref)
 
 
 def test_module_surface():
