@@ -17,8 +17,12 @@ template <int BM, int BN, int WM, int WN, int VEC>
 __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AI = BM / 32, BI = BN / 32;      // float4 chunks per thread per K tile
-    __shared__ __attribute__((aligned(16))) float As[BM * LDS_PITCH];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_PITCH];
+    // one LDS array: [A tile | B tile] during the K loop, re-used as the per-wave output staging area in the epilogue
+    constexpr int SP = TN * 32 + 4;                       // staging row pitch (floats)
+    constexpr int LDS_FLOATS = (BM + BN) * LDS_PITCH > 4 * 32 * SP ? (BM + BN) * LDS_PITCH : 4 * 32 * SP;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    float* const As = lds;
+    float* const Bs = lds + BM * LDS_PITCH;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -185,23 +189,60 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5): a direct store is 16*TM*TN
+    // scalar store instructions per lane (store-issue bound when K is short).  Instead every wave transposes one 32 x (32*TN)
+    // row block at a time through its private LDS staging area and writes float4 per lane: 4x fewer store instructions and
+    // 128*TN-byte contiguous row segments.  (The last __syncthreads() of the K loop already fenced the A/B tiles.)
+    {
+        constexpr int CQ = TN * 8;                    // float4 chunks per staged row
+        constexpr int RPP = 64 / CQ;                  // rows per pass
+        float* const stg = lds + wave * 32 * SP;
+        const int rr = lane / CQ, cq = lane % CQ;
+        const int col = n0 + wn * TN * 32 + cq * 4;   // this lane's 4 output columns (fixed for all passes)
+        const bool vec_ok = !(p.ldc & 3) && !((uintptr_t)C & 15) && (!p.addend || (!(p.ld_add & 3) && !((uintptr_t)p.addend & 15)));
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-        if (col >= p.N) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
+            for (int e = 0; e < 4; ++e)
+                if (col + e < p.N) bv[e] = p.bias[col + e];
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (p.addend) v += p.addend[(int64_t)row * p.ld_add + col];
-                if (p.act == CORRIF_ACT_RELU) v = fmaxf(v, 0.f);
-                else if (p.act == CORRIF_ACT_GELU) v = gelu_erf(v);
-                C[(int64_t)row * p.ldc + col] = v;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SP + j * 32 + (lane & 31)] = acc[i][j][r];
+            // same wave wrote and reads: LDS ops of one wave complete in order, no barrier needed
+#pragma unroll
+            for (int ps = 0; ps < 32 / RPP; ++ps) {
+                const int lr = ps * RPP + rr;
+                const int row = m0 + (wm * TM + i) * 32 + lr;
+                f32x4 v = *reinterpret_cast<const f32x4*>(&stg[lr * SP + cq * 4]);
+                if (row >= p.M || col >= p.N) continue;
+                v += bv;
+                float* __restrict__ dst = C + (int64_t)row * p.ldc + col;
+                if (vec_ok && col + 3 < p.N) {
+                    if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + (int64_t)row * p.ld_add + col);
+                    if (p.act == CORRIF_ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    } else if (p.act == CORRIF_ACT_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    }
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (col + e >= p.N) break;
+                        float x = v[e];
+                        if (p.addend) x += p.addend[(int64_t)row * p.ld_add + col + e];
+                        if (p.act == CORRIF_ACT_RELU) x = fmaxf(x, 0.f);
+                        else if (p.act == CORRIF_ACT_GELU) x = gelu_erf(x);
+                        dst[e] = x;
+                    }
+                }
             }
         }
     }
