@@ -220,21 +220,47 @@ class Decoder_fuse(nn.Module):
         self.RFM2 = fusion_prenorm(b * 6)
         self.RFM1 = fusion_prenorm(b * 3)
         self.final_conv = Conv3dP(8, 3, 1)
+        self.concurrent_skips = True
+        self._side = None
 
     def forward(self, x1, x2, x3, x4, x5):
         B, dev = x5.shape[0], x5.device
-        y = self.RFM5_reduce(self.RFM5(x5))
         stages = ((self.RFM4, x4, 16, self.d4_c1, self.d4_c2, self.d4_out),
                   (self.RFM3, x3, 32, self.d3_c1, self.d3_c2, self.d3_out),
                   (self.RFM2, x2, 64, self.d2_c1, self.d2_c2, self.d2_out),
                   (self.RFM1, x1, 128, self.d1_c1, self.d1_c2, self.d1_out))
-        for rfm, skip, n, c1, c2, cout in stages:
-            cs, cy = skip.shape[-1], c1.conv.weight.shape[0]
-            cat = torch.empty((B, n, n, n, cs + cy), dtype=torch.float32, device=dev)
+        cats = [torch.empty((B, n, n, n, skip.shape[-1] + c1.conv.weight.shape[0]), dtype=torch.float32, device=dev)
+                for _, skip, n, c1, _, _ in stages]
+        # skip branches (RFM -> nearest upsample into the concat slice) only depend on the early-fusion outputs: run them on a
+        # side stream next to the main chain (RFM5 -> up2 -> d*_c1 ...), which needs each of them only at its concat
+        parts_s = [None] * 4
+        side = self._side if getattr(self, "_side", None) is not None else None
+        use_side = self.concurrent_skips and x5.is_cuda
+        if use_side:
+            cur = torch.cuda.current_stream()
+            if side is None:
+                side = self._side = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur)
+            events = []
+            with torch.cuda.stream(side):
+                for l, (rfm, skip, n, _, _, _) in enumerate(stages):
+                    cs = skip.shape[-1]
+                    parts_s[l] = ops.nearest(rfm(skip), (n, n, n), out=cats[l][..., :cs])     # F.interpolate nearest (mmvit4.py:271-286)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    events.append(ev)
+        y = self.RFM5_reduce(self.RFM5(x5))
+        for l, (rfm, skip, n, c1, c2, cout) in enumerate(stages):
+            cs = skip.shape[-1]
+            cat = cats[l]
             up = ops.trilinear(y, (n, n, n))                                   # self.up2, align_corners (mmvit4.py:243)
             part_y = c1(up, out=cat[..., cs:])                                 # d*_c1: 3x3x3 replicate -> ReLU -> IN
-            part_s = ops.nearest(rfm(skip), (n, n, n), out=cat[..., :cs])      # F.interpolate nearest (mmvit4.py:271-286)
-            y = cout(c2(ops.cat_channels(cat, part_s, part_y)))
+            if use_side:
+                torch.cuda.current_stream().wait_event(events[l])
+                parts_s[l].record_stream(torch.cuda.current_stream())
+            else:
+                parts_s[l] = ops.nearest(rfm(skip), (n, n, n), out=cat[..., :cs])
+            y = cout(c2(ops.cat_channels(cat, parts_s[l], part_y)))
         up = ops.trilinear(y, (1, 224, 224))                                   # up_to_224 (mmvit4.py:263): depth slice 0 only
         return ops.head(up, self.final_conv.weight, self.final_conv.bias)      # final_conv + sigmoid (mmvit4.py:290-291)
 
