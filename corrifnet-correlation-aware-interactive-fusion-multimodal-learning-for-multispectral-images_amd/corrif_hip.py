@@ -63,6 +63,10 @@ _SIGS = {
     "corrif_conv3_patch_wgrad": (i32, [C.POINTER(Conv3PatchWgrad), ptr]),
     "corrif_conv3_patch_wgrad_workspace": (C.c_size_t, [i32, i32]),
     "corrif_conv3_patch_wgrad_slots": (i32, [i32, i32]),
+    "corrif_conv1x1_small_supported": (i32, [i32, i32]),
+    "corrif_conv1x1_small_fwd": (i32, [ptr, i64, ptr, i32, ptr, ptr, i64, i64, i32, i32, ptr]),
+    "corrif_conv1x1_small_wgrad": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i32, i32, ptr]),
+    "corrif_conv1x1_small_workspace": (C.c_size_t, [i64, i32, i32]),
     "corrif_slab_reduce": (i32, [ptr, ptr, i64, i32, ptr]),
     "corrif_col_sum": (i32, [ptr, i64, i64, i32, ptr, ptr, ptr]),
     "corrif_col_sum_workspace": (C.c_size_t, [i64, i32]),
@@ -84,6 +88,8 @@ _SIGS = {
     "corrif_pad_fold": (i32, [ptr, ptr, i64, i32, i32, i32, i32, i32, ptr]),
     "corrif_softmax_rows": (i32, [ptr, i64, i32, f32, ptr]),
     "corrif_softmax_rows_bwd": (i32, [ptr, ptr, i64, i32, f32, ptr]),
+    "corrif_softmax_dropout_rows": (i32, [ptr, ptr, i64, i32, f32, f32, u64, u64, ptr]),
+    "corrif_softmax_dropout_rows_bwd": (i32, [ptr, ptr, i64, i32, f32, f32, u64, u64, ptr]),
     "corrif_dropout": (i32, [ptr, ptr, i64, f32, u64, u64, ptr]),
     "corrif_add": (i32, [ptr, ptr, ptr, i64, ptr]),
     "corrif_add_bcast_rows": (i32, [ptr, ptr, i64, ptr, i64, ptr]),

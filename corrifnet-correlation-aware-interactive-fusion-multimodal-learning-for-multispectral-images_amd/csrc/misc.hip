@@ -466,6 +466,26 @@ extern "C" int corrif_pad_fold(const float* dxp, float* dx, int64_t lddx, int32_
     return CORRIF_OK;
 }
 
+// ------------------------------------------------------------------ Philox4x32-10 (shared by dropout and the fused softmax+dropout)
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t seed, uint32_t (&out)[4]) {
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[e] = c[e];
+}
 // ------------------------------------------------------------------ row softmax (one wave per row, row kept in registers)
 __device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
@@ -500,6 +520,78 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s
     const float inv = 1.0f / wave_sum_f(sum);
 #pragma unroll
     for (int k = 0; k < NV; ++k) *reinterpret_cast<f32x4*>(s + row * n + (k * 64 + lane) * 4) = v[k] * inv;
+}
+// softmax + attention dropout in one pass: P (kept for the backward) and P' = P * keep/(1-p) (fed to the P.V product)
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_dropout_rows_kernel(float* __restrict__ s, float* __restrict__ pd, int64_t rows, float scale,
+                                                                   float pdrop, float inv_keep, uint64_t seed, uint64_t offset4) {
+    constexpr int n = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    f32x4 v[NV];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        v[k] = *reinterpret_cast<const f32x4*>(s + row * n + (k * 64 + lane) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[k][e] *= scale; m = fmaxf(m, v[k][e]); }
+    }
+    m = wave_max_f(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[k][e] = expf(v[k][e] - m); sum += v[k][e]; }
+    const float inv = 1.0f / wave_sum_f(sum);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int64_t idx4 = (row * n) / 4 + k * 64 + lane;
+        f32x4 pv = v[k] * inv;
+        *reinterpret_cast<f32x4*>(s + idx4 * 4) = pv;
+        uint32_t r[4];
+        philox4x32_10(offset4 + (uint64_t)idx4, seed, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float u = (float)(r[e] >> 8) * (1.0f / 16777216.0f);
+            pv[e] = (u >= pdrop) ? pv[e] * inv_keep : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(pd + idx4 * 4) = pv;
+    }
+}
+// backward of the pair: g = dP' * keep/(1-p) ; dS = scale * P * (g - sum(P*g)), in place on the dP' buffer
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_dropout_rows_bwd_kernel(const float* __restrict__ p, float* __restrict__ g, int64_t rows,
+                                                                       float scale, float pdrop, float inv_keep, uint64_t seed,
+                                                                       uint64_t offset4) {
+    constexpr int n = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    f32x4 pv[NV], gv[NV];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int64_t idx4 = (row * n) / 4 + k * 64 + lane;
+        pv[k] = *reinterpret_cast<const f32x4*>(p + idx4 * 4);
+        gv[k] = *reinterpret_cast<const f32x4*>(g + idx4 * 4);
+        uint32_t r[4];
+        philox4x32_10(offset4 + (uint64_t)idx4, seed, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float u = (float)(r[e] >> 8) * (1.0f / 16777216.0f);
+            gv[k][e] = (u >= pdrop) ? gv[k][e] * inv_keep : 0.f;
+            dot += pv[k][e] * gv[k][e];
+        }
+    }
+    dot = wave_sum_f(dot);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = scale * pv[k][e] * (gv[k][e] - dot);
+        *reinterpret_cast<f32x4*>(g + row * n + (k * 64 + lane) * 4) = o;
+    }
 }
 template <int NV>
 __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ p, float* __restrict__ g, int64_t rows, float scale) {
@@ -538,6 +630,34 @@ extern "C" int corrif_softmax_rows(float* s, int64_t rows, int32_t n, float scal
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
+extern "C" int corrif_softmax_dropout_rows(float* s, float* pd, int64_t rows, int32_t n, float scale, float p, uint64_t seed, uint64_t offset,
+                                           void* stream) {
+    if (!s || !pd || rows <= 0 || !(p >= 0.f && p < 1.f)) return CORRIF_EINVAL;
+    if (!al16(s) || !al16(pd) || (offset & 3)) return CORRIF_EUNSUPPORTED;
+    dim3 grid((unsigned)((rows + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    const float ik = 1.0f / (1.0f - p);
+    if (n == 512) hipLaunchKernelGGL((softmax_dropout_rows_kernel<2>), grid, dim3(256), 0, st, s, pd, rows, scale, p, ik, seed, offset / 4);
+    else if (n == 1024) hipLaunchKernelGGL((softmax_dropout_rows_kernel<4>), grid, dim3(256), 0, st, s, pd, rows, scale, p, ik, seed, offset / 4);
+    else if (n == 2048) hipLaunchKernelGGL((softmax_dropout_rows_kernel<8>), grid, dim3(256), 0, st, s, pd, rows, scale, p, ik, seed, offset / 4);
+    else return CORRIF_EUNSUPPORTED;
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}
+extern "C" int corrif_softmax_dropout_rows_bwd(const float* pr, float* dpd_to_ds, int64_t rows, int32_t n, float scale, float p, uint64_t seed,
+                                               uint64_t offset, void* stream) {
+    if (!pr || !dpd_to_ds || rows <= 0 || !(p >= 0.f && p < 1.f)) return CORRIF_EINVAL;
+    if (!al16(pr) || !al16(dpd_to_ds) || (offset & 3)) return CORRIF_EUNSUPPORTED;
+    dim3 grid((unsigned)((rows + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    const float ik = 1.0f / (1.0f - p);
+    if (n == 512) hipLaunchKernelGGL((softmax_dropout_rows_bwd_kernel<2>), grid, dim3(256), 0, st, pr, dpd_to_ds, rows, scale, p, ik, seed, offset / 4);
+    else if (n == 1024) hipLaunchKernelGGL((softmax_dropout_rows_bwd_kernel<4>), grid, dim3(256), 0, st, pr, dpd_to_ds, rows, scale, p, ik, seed, offset / 4);
+    else if (n == 2048) hipLaunchKernelGGL((softmax_dropout_rows_bwd_kernel<8>), grid, dim3(256), 0, st, pr, dpd_to_ds, rows, scale, p, ik, seed, offset / 4);
+    else return CORRIF_EUNSUPPORTED;
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}
 extern "C" int corrif_softmax_rows_bwd(const float* p, float* dp_to_ds, int64_t rows, int32_t n, float scale, void* stream) {
     if (!p || !dp_to_ds || rows <= 0) return CORRIF_EINVAL;
     if (!al16(p) || !al16(dp_to_ds)) return CORRIF_EUNSUPPORTED;
@@ -553,25 +673,6 @@ extern "C" int corrif_softmax_rows_bwd(const float* p, float* dp_to_ds, int64_t 
 }
 
 // ------------------------------------------------------------------ dropout, Philox4x32-10 counter stream
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-    uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
-    uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t seed, uint32_t (&out)[4]) {
-    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        philox_round(c, k0, k1);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) out[e] = c[e];
-}
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n4, float p, float inv_keep, uint64_t seed,
                                uint64_t offset4) {
     GRID_STRIDE(i, n4) {
@@ -941,6 +1042,127 @@ extern "C" int corrif_adam_step(float* p, const float* g, float* m, float* v, in
     double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)((double)lr / bc1), beta1, beta2, eps,
                        weight_decay, (float)sqrt(bc2));
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}
+
+// ------------------------------------------------------------------ tiny-channel 1x1x1 convolution (Ci, Co <= 16)
+// d1_out / d2_out (8->8, 16->16 on 128^3 / 64^3 grids, mmvit4.py:233,236) have 2-4 FLOP/B: pure HBM streams.  One thread
+// per voxel, weights broadcast from LDS, float4 I/O.  The same kernel is the data gradient (transposed weights).
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void conv1x1_small_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                                            int w_transposed, const float* __restrict__ bias, float* __restrict__ y,
+                                                            int64_t ldy, int64_t rows) {
+    __shared__ float ws[CO * CI + CO];
+    for (int i = threadIdx.x; i < CO * CI; i += 256) {
+        int co = i / CI, ci = i - co * CI;
+        ws[i] = w_transposed ? w[ci * CO + co] : w[i];          // ws[co][ci]
+    }
+    for (int i = threadIdx.x; i < CO; i += 256) ws[CO * CI + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    GRID_STRIDE(r, rows) {
+        float xv[CI];
+#pragma unroll
+        for (int c = 0; c < CI; c += 4) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+            xv[c] = v[0]; xv[c + 1] = v[1]; xv[c + 2] = v[2]; xv[c + 3] = v[3];
+        }
+#pragma unroll
+        for (int o = 0; o < CO; o += 4) {
+            f32x4 acc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = ws[CO * CI + o + e];
+#pragma unroll
+                for (int c = 0; c < CI; ++c) a = fmaf(xv[c], ws[(o + e) * CI + c], a);
+                acc[e] = a;
+            }
+            *reinterpret_cast<f32x4*>(y + r * ldy + o) = acc;
+        }
+    }
+}
+// dW[co][ci] = sum_r dy[r][co] x[r][ci], db[co] = sum_r dy[r][co]: per-thread register tile, wave butterfly, block partials (double)
+template <int CI, int CO>   // blockIdx.y selects a slice of 8 output channels (keeps the register tile at 8*CI + 8 floats)
+__global__ __launch_bounds__(256) void conv1x1_small_wgrad_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
+                                                                  int64_t lddy, int64_t rows, double* __restrict__ part) {
+    constexpr int OT = 8, NA = OT * CI + OT, NT = CO * CI + CO;
+    __shared__ float red[4][NA];
+    const int o0 = blockIdx.y * OT;
+    float acc[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = 0.f;
+    int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+    int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+        float xv[CI], gv[OT];
+#pragma unroll
+        for (int c = 0; c < CI; c += 4) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+            xv[c] = v[0]; xv[c + 1] = v[1]; xv[c + 2] = v[2]; xv[c + 3] = v[3];
+        }
+#pragma unroll
+        for (int o = 0; o < OT; o += 4) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(dy + r * lddy + o0 + o);
+            gv[o] = v[0]; gv[o + 1] = v[1]; gv[o + 2] = v[2]; gv[o + 3] = v[3];
+        }
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+#pragma unroll
+            for (int c = 0; c < CI; ++c) acc[o * CI + c] = fmaf(gv[o], xv[c], acc[o * CI + c]);
+            acc[OT * CI + o] += gv[o];
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wv][i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NA; i += 256) {
+        const double s = (double)red[0][i] + (double)red[1][i] + (double)red[2][i] + (double)red[3][i];
+        const int dst = i < OT * CI ? (o0 * CI + i) : (CO * CI + o0 + (i - OT * CI));     // dW[o0*CI + ...] | db[o0 + ...]
+        part[(int64_t)blockIdx.x * NT + dst] = s;
+    }
+}
+__global__ void conv1x1_small_wgrad_final_kernel(const double* __restrict__ part, int nb, int n_w, int n_b, float* __restrict__ dw,
+                                                 float* __restrict__ db) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_w + n_b) return;
+    double s = 0;
+    for (int k = 0; k < nb; ++k) s += part[(int64_t)k * (n_w + n_b) + i];
+    if (i < n_w) dw[i] = (float)s;
+    else if (db) db[i - n_w] = (float)s;
+}
+static int small1x1_blocks(int64_t rows) { int64_t b = (rows + 2047) / 2048; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
+extern "C" int corrif_conv1x1_small_supported(int32_t Ci, int32_t Co) { return (Ci == Co) && (Ci == 8 || Ci == 16); }
+extern "C" size_t corrif_conv1x1_small_workspace(int64_t rows, int32_t Ci, int32_t Co) {
+    return (size_t)small1x1_blocks(rows) * (Ci * Co + Co) * sizeof(double);
+}
+extern "C" int corrif_conv1x1_small_fwd(const float* x, int64_t ldx, const float* w, int32_t w_transposed, const float* bias, float* y,
+                                        int64_t ldy, int64_t rows, int32_t Ci, int32_t Co, void* stream) {
+    if (!x || !w || !y || rows <= 0) return CORRIF_EINVAL;
+    if (!corrif_conv1x1_small_supported(Ci, Co) || (ldx & 3) || (ldy & 3) || !al16(x) || !al16(y)) return CORRIF_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned nb = nblocks(rows, 256, 16384);
+    if (Ci == 8) hipLaunchKernelGGL((conv1x1_small_kernel<8, 8>), dim3(nb), dim3(256), 0, s, x, ldx, w, (int)w_transposed, bias, y, ldy, rows);
+    else hipLaunchKernelGGL((conv1x1_small_kernel<16, 16>), dim3(nb), dim3(256), 0, s, x, ldx, w, (int)w_transposed, bias, y, ldy, rows);
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}
+extern "C" int corrif_conv1x1_small_wgrad(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dw, float* db, double* ws,
+                                          int64_t rows, int32_t Ci, int32_t Co, void* stream) {
+    if (!x || !dy || !dw || !ws || rows <= 0) return CORRIF_EINVAL;
+    if (!corrif_conv1x1_small_supported(Ci, Co) || (ldx & 3) || (lddy & 3) || !al16(x) || !al16(dy)) return CORRIF_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    int nb = small1x1_blocks(rows);
+    if (Ci == 8) hipLaunchKernelGGL((conv1x1_small_wgrad_kernel<8, 8>), dim3(nb, 1), dim3(256), 0, s, x, ldx, dy, lddy, rows, ws);
+    else hipLaunchKernelGGL((conv1x1_small_wgrad_kernel<16, 16>), dim3(nb, 2), dim3(256), 0, s, x, ldx, dy, lddy, rows, ws);
+    CORRIF_CHECK_LAUNCH();
+    const int n = Ci * Co + Co;
+    hipLaunchKernelGGL(conv1x1_small_wgrad_final_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double*)ws, nb, Ci * Co, (int)Co, dw, db);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }

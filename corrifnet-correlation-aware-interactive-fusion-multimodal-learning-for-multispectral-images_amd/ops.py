@@ -167,6 +167,8 @@ class ConvFn(Function):
             wp = repack(weight, (Co, Kp), Co, 1, T, 0, Kp, zero=True)
             geom = H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad, ntaps=T, src_batch_pitch=batch_pitch)
             gemm(P(x), 1, P(wp), Kp, 0, P(y), ldc, M, Co, Kp, 1, geom, bias=P(bias) if bias is not None else None, act=act)
+        elif is_gemm and act == ACT_NONE and lib().corrif_conv1x1_small_supported(Ci, Co):
+            check(lib().corrif_conv1x1_small_fwd(P(x), lda, P(weight), 0, P(bias), P(y), ldc, M, Ci, Co, stream()), "corrif_conv1x1_small_fwd")
         elif _patch_cc((kd, kh, kw), stride, pad, Ci, Co) and act == ACT_NONE:
             cc = _patch_cc((kd, kh, kw), stride, pad, Ci, Co)
             wp = repack(weight, (Ci // cc, Co, T, cc), Co, Ci, T, 3, cc)
@@ -191,7 +193,9 @@ class ConvFn(Function):
         if ctx.needs_input_grad[0] and not stem:
             gx = torch.empty((B, Di, Hi, Wi, Ci), dtype=torch.float32, device=dev)
             Min = B * Di * Hi * Wi
-            if is_gemm:        # dX[M,Ci] = dY[M,Co] . W[Co,Ci]   (W is the [K][N] operand as stored)
+            if is_gemm and lib().corrif_conv1x1_small_supported(Ci, Co):
+                check(lib().corrif_conv1x1_small_fwd(P(gy), ldg, P(weight), 1, 0, P(gx), Ci, Min, Co, Ci, stream()), "corrif_conv1x1_small_fwd")
+            elif is_gemm:      # dX[M,Ci] = dY[M,Co] . W[Co,Ci]   (W is the [K][N] operand as stored)
                 gemm(P(gy), ldg, P(weight), Ci, 1, P(gx), Ci, Min, Ci, Co, Co, H.gemm_geom())
             elif _patch_cc((kd, kh, kw), stride, pad, Co, Ci):      # data gradient = patch conv of dY with flipped weights
                 cc = _patch_cc((kd, kh, kw), stride, pad, Co, Ci)
@@ -215,6 +219,13 @@ class ConvFn(Function):
                 else:
                     geom = H.conv_geom((Di, Hi, Wi), (Do, Ho, Wo), (kd, kh, kw), stride, pad, transposed=True)
                     gemm(P(gy), ldg, P(wd), Ci, 1, P(gx), Ci, Min, Ci, T * Co, Co, geom)
+        small11 = is_gemm and lib().corrif_conv1x1_small_supported(Ci, Co)
+        if small11 and ctx.needs_input_grad[1]:      # weight and bias gradient in one streaming pass
+            gw = torch.empty(weight.shape, dtype=torch.float32, device=dev)
+            gb = torch.empty(Co, dtype=torch.float32, device=dev) if has_bias else None
+            ws = _ws(lib().corrif_conv1x1_small_workspace(M, Ci, Co), dev)
+            check(lib().corrif_conv1x1_small_wgrad(P(x), lda, P(gy), ldg, P(gw), P(gb), P(ws), M, Ci, Co, stream()), "corrif_conv1x1_small_wgrad")
+            return gx, gw, gb, None, None, None, None, None
         if ctx.needs_input_grad[1]:
             if stem:
                 Kp = (T + 3) // 4 * 4
@@ -537,14 +548,15 @@ class AttentionFn(Function):
         gg = H.gemm_geom()
         # S[b,h] = Q K^T : A = q rows (pitch 3C), B = k rows [N][hd] (pitch 3C)
         gemm(q_ptr, C3, k_ptr, C3, 0, P(S), N, N, N, hd, hd, gg, Z=Z, Zi=heads, sA=(N * C3, hd), sB=(N * C3, hd), sC=(heads * N * N, N * N))
-        check(lib().corrif_softmax_rows(P(S), Z * N, N, scale, stream()), "corrif_softmax_rows")
         drop = training and p_drop > 0.0
         Pd = S
         seed = off = 0
-        if drop:
+        if drop:                # softmax and attention dropout in one pass over the scores
             seed, off = _Philox.reserve(S.numel())
             Pd = torch.empty_like(S)
-            check(lib().corrif_dropout(P(S), P(Pd), S.numel(), p_drop, seed, off, stream()), "corrif_dropout")
+            check(lib().corrif_softmax_dropout_rows(P(S), P(Pd), Z * N, N, scale, p_drop, seed, off, stream()), "corrif_softmax_dropout_rows")
+        else:
+            check(lib().corrif_softmax_rows(P(S), Z * N, N, scale, stream()), "corrif_softmax_rows")
         out = torch.empty((B, N, C), dtype=torch.float32, device=dev)
         # O[b,:,h,:] = P V : B operand is V as [K = tokens][N = hd] (layout 1, pitch 3C)
         gemm(P(Pd), N, v_ptr, C3, 1, P(out), C, N, hd, N, N, gg, Z=Z, Zi=heads, sA=(heads * N * N, N * N), sB=(N * C3, hd), sC=(N * C, hd))
@@ -578,8 +590,9 @@ class AttentionFn(Function):
         dP = Pd if drop else torch.empty_like(S)
         gemm(P(go), C, v_ptr, C3, 0, P(dP), N, N, N, hd, hd, gg, Z=Z, Zi=heads, sA=(N * C, hd), sB=(N * C3, hd), sC=(heads * N * N, N * N))
         if drop:
-            check(lib().corrif_dropout(P(dP), P(dP), dP.numel(), p_drop, seed, off, stream()), "corrif_dropout")
-        check(lib().corrif_softmax_rows_bwd(P(S), P(dP), Z * N, N, scale, stream()), "corrif_softmax_rows_bwd")
+            check(lib().corrif_softmax_dropout_rows_bwd(P(S), P(dP), Z * N, N, scale, p_drop, seed, off, stream()), "corrif_softmax_dropout_rows_bwd")
+        else:
+            check(lib().corrif_softmax_rows_bwd(P(S), P(dP), Z * N, N, scale, stream()), "corrif_softmax_rows_bwd")
         # dQ = dS K ; dK = dS^T Q
         gemm(P(dP), N, k_ptr, C3, 1, dq_ptr, C3, N, hd, N, N, gg, Z=Z, Zi=heads, sA=(heads * N * N, N * N), sB=(N * C3, hd), sC=(N * C3, hd))
         wgrad(P(dP), N, q_ptr, C3, hd, dk_ptr, C3, N, N, hd, gg, dev, Z=Z, Zi=heads, sA=(heads * N * N, N * N), sB=(N * C3, hd), sC=(N * C3, hd))

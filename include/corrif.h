@@ -148,6 +148,16 @@ int corrif_conv3_patch_wgrad(const CorrifConv3PatchWgrad* p, void* stream);
 size_t corrif_conv3_patch_wgrad_workspace(int32_t Ci, int32_t Co);   /* host-only; 0 = shape not supported */
 int corrif_conv3_patch_wgrad_slots(int32_t Ci, int32_t Co);          /* host-only */
 
+/* Tiny-channel 1x1x1 convolution, Ci = Co in {8, 16}: d1_out / d2_out (mmvit4.py:233,236), 2-4 FLOP/B -> pure HBM stream, one
+ * voxel per thread, weights broadcast from LDS.  w_transposed = 1 makes it the data gradient (dX = dY . W).  The weight-gradient
+ * entry also produces the bias gradient. */
+int corrif_conv1x1_small_supported(int32_t Ci, int32_t Co);   /* host-only */
+int corrif_conv1x1_small_fwd(const float* x, int64_t ldx, const float* w, int32_t w_transposed, const float* bias, float* y, int64_t ldy,
+                             int64_t rows, int32_t Ci, int32_t Co, void* stream);
+int corrif_conv1x1_small_wgrad(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dw, float* db, double* ws,
+                               int64_t rows, int32_t Ci, int32_t Co, void* stream);
+size_t corrif_conv1x1_small_workspace(int64_t rows, int32_t Ci, int32_t Co);
+
 /* Stem: Conv3d(1->64,(3,7,7),stride (1,2,2),pad (1,3,3), no bias) on x[:, m] of the NCDHW input
  * (mmvit4.py:120,172; aten::convolution with Cin = 1) runs through corrif_gemm_fwd / corrif_wgrad
  * with Cs = 1 (scalar gather): lda = 1, g.src_batch_pitch = 3*D*H*W, K padded 147 -> 148 with
@@ -220,6 +230,12 @@ int corrif_pad_fold(const float* dxp, float* dx, int64_t lddx, int32_t B, int32_
  * and its backward ds = scale * p * (dp - sum(dp*p)) (aten::_softmax_backward_data). */
 int corrif_softmax_rows(float* s, int64_t rows, int32_t n, float scale, void* stream);
 int corrif_softmax_rows_bwd(const float* p, float* dp_to_ds, int64_t rows, int32_t n, float scale, void* stream);
+
+/* softmax + attention dropout fused (mmvit4.py:310-311): s <- P = softmax(s*scale) in place (kept for the backward), pd <- P * keep/(1-p)
+ * with the same Philox stream and element indexing as corrif_dropout(offset); backward: dS = scale*P*(g - sum(P*g)), g = dP'*keep/(1-p). */
+int corrif_softmax_dropout_rows(float* s, float* pd, int64_t rows, int32_t n, float scale, float p, uint64_t seed, uint64_t offset, void* stream);
+int corrif_softmax_dropout_rows_bwd(const float* pr, float* dpd_to_ds, int64_t rows, int32_t n, float scale, float p, uint64_t seed,
+                                    uint64_t offset, void* stream);
 
 /* Dropout with a counter-based Philox4x32-10 stream (replaces aten::bernoulli_/native_dropout at
  * mmvit4.py:302,304,336,353,355): y = x * keep/(1-p), keep = u(seed, offset + i) >= p.

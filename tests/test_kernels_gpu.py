@@ -58,6 +58,7 @@ CONVS = [
     ("3x3x3_rep_d2", 8, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (2, 2, 17, 33), False),
     ("3x3x3_zero_48", 48, 48, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, (1, 4, 10, 10), True),
     ("1x1_12_to_4", 12, 4, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 5, 6, 7), True),
+    ("1x1_16_16", 16, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 7, 9, 11), True),
     ("1x1_n8", 8, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 6, 6, 6), True),
     ("1x1_wide", 2048, 192, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (1, 4, 4, 4), True),
 ]
@@ -281,6 +282,29 @@ def test_attention(ops, B, N):
     torch.cuda.synchronize()
     assert rel(og, outr) < 3e-6
     assert rel(qg.grad, qr.grad) < 1e-5
+
+
+def test_attention_dropout_fused_equals_unfused(ops):
+    """the fused softmax+dropout kernels use the same Philox stream / indexing as the element-wise dropout kernel"""
+    B, N, heads, C = 2, 512, 8, 512
+    qkv = rnd(B, N, 3 * C, seed=3, scale=0.5).to(DEV)
+    go = rnd(B, N, C, seed=4).to(DEV)
+    ops.manual_seed(77)
+    q1 = qkv.clone().requires_grad_()
+    o1 = ops.attention(q1, heads, 0.1, True)
+    o1.backward(go)
+    # unfused statement of the same computation with the stand-alone kernels
+    ops.manual_seed(77)
+    q2 = qkv.clone().requires_grad_()
+    qq, kk, vv = q2.reshape(B, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+    P_ = torch.softmax((qq @ kk.transpose(-2, -1)) * (C // heads) ** -0.5, -1)
+    Pd = ops.dropout(P_.contiguous(), 0.1, True)
+    o2 = (Pd @ vv).transpose(1, 2).reshape(B, N, C)
+    o2.backward(go)
+    torch.cuda.synchronize()
+    assert rel(o1, o2) < 3e-6
+    assert rel(q1.grad, q2.grad) < 2e-5
+    assert (o1 - ops.attention(qkv, heads, 0.1, False)).abs().max().item() > 1e-3     # dropout really is active
 
 
 @pytest.mark.parametrize("B", [1, 2, 3, 4])
