@@ -148,6 +148,9 @@ def main():
 
     torch.manual_seed(0)
     model = mmvit4.MMVit4().to(dev).train()
+    if os.environ.get("CORRIF_SERIAL") == "1":          # profiling aid: one stream, clean per-kernel attribution
+        model.concurrent_branches = False
+        model.decoder_fuse.concurrent_skips = False
     broadcast_module_state(model)
     reducer = GradAllReducer(model)
     B = args.batch

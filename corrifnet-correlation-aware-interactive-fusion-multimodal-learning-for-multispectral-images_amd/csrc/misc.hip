@@ -24,9 +24,16 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
         reinterpret_cast<f32x4*>(y)[i] = av + bv;
     }
 }
+__global__ void add_scalar_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n) {
+    GRID_STRIDE(i, n) y[i] = a[i] + b[i];
+}
 extern "C" int corrif_add(const float* a, const float* b, float* y, int64_t n, void* stream) {
     if (!a || !b || !y || n <= 0) return CORRIF_EINVAL;
-    if ((n & 3) || !al16(a) || !al16(b) || !al16(y)) return CORRIF_EUNSUPPORTED;
+    if ((n & 3) || !al16(a) || !al16(b) || !al16(y)) {      // odd sizes / unaligned views (gradient buckets): scalar path
+        hipLaunchKernelGGL(add_scalar_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, n);
+        CORRIF_CHECK_LAUNCH();
+        return CORRIF_OK;
+    }
     hipLaunchKernelGGL(add_kernel, dim3(nblocks(n / 4)), dim3(256), 0, (hipStream_t)stream, a, b, (int64_t)0, y, n / 4);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
@@ -1136,7 +1143,7 @@ __global__ void conv1x1_small_wgrad_final_kernel(const double* __restrict__ part
     if (i < n_w) dw[i] = (float)s;
     else if (db) db[i - n_w] = (float)s;
 }
-static int small1x1_blocks(int64_t rows) { int64_t b = (rows + 2047) / 2048; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
+static int small1x1_blocks(int64_t rows) { int64_t b = (rows + 2047) / 2048; return (int)(b > 512 ? 512 : (b < 1 ? 1 : b)); }
 extern "C" int corrif_conv1x1_small_supported(int32_t Ci, int32_t Co) { return (Ci == Co) && (Ci == 8 || Ci == 16); }
 extern "C" size_t corrif_conv1x1_small_workspace(int64_t rows, int32_t Ci, int32_t Co) {
     return (size_t)small1x1_blocks(rows) * (Ci * Co + Co) * sizeof(double);
