@@ -186,6 +186,7 @@ static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 extern "C" int corrif_conv3_patch_cc(int32_t Ci, int32_t Co) {
     if (Co <= 0 || Co > 32 || (Co & 3) || Ci <= 0 || (Ci & 7)) return 0;
+    if (Ci > 64) return 0;      // many channel chunks re-stage the halo too often: the implicit GEMM is faster there (d3_c2: 50 vs 38 TF/s)
     return (Co <= 8 && !(Ci & 15)) ? 16 : 8;
 }
 
