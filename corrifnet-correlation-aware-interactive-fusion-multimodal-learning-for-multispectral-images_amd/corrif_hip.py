@@ -108,6 +108,7 @@ _SIGS = {
     "corrif_bce_workspace": (C.c_size_t, [i64]),
     "corrif_jaccard": (i32, [ptr, ptr, i64, f32, ptr, ptr, ptr]),
     "corrif_jaccard_workspace": (C.c_size_t, [i64]),
+    "corrif_adam_multi": (i32, [ptr, ptr, ptr, i32, f32, f32, f32, f32, f32, i32, ptr]),
     "corrif_adam_step": (i32, [ptr, ptr, ptr, ptr, i64, f32, f32, f32, f32, f32, i32, ptr]),
 }
 EXPORTS = tuple(_SIGS)

@@ -1173,3 +1173,34 @@ extern "C" int corrif_conv1x1_small_wgrad(const float* x, int64_t ldx, const flo
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
+
+// ------------------------------------------------------------------ multi-tensor Adam: one launch for all parameters
+// table entry per tensor: {p, g, m, v, n}; block b works on chunk blk_off[b] (1024 elements) of tensor blk_tensor[b]
+struct AdamEntry { float* p; const float* g; float* m; float* v; int64_t n; };
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamEntry* __restrict__ tab, const int* __restrict__ blk_tensor,
+                                                         const int64_t* __restrict__ blk_off, float step_size, float beta1, float beta2,
+                                                         float eps, float wd, float bc2_sqrt) {
+    const AdamEntry e = tab[blk_tensor[blockIdx.x]];
+    const int64_t base = blk_off[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        if (i >= e.n) break;
+        float gv = e.g[i];
+        if (wd != 0.f) gv += wd * e.p[i];
+        const float mv = e.m[i] + (1.0f - beta1) * (gv - e.m[i]);
+        const float vv = beta2 * e.v[i] + (1.0f - beta2) * gv * gv;
+        e.m[i] = mv;
+        e.v[i] = vv;
+        e.p[i] -= step_size * (mv / (sqrtf(vv) / bc2_sqrt + eps));
+    }
+}
+extern "C" int corrif_adam_multi(const void* table, const int32_t* blk_tensor, const int64_t* blk_off, int32_t nblocks_, float lr, float beta1,
+                                 float beta2, float eps, float weight_decay, int32_t step, void* stream) {
+    if (!table || !blk_tensor || !blk_off || nblocks_ <= 0 || step < 1) return CORRIF_EINVAL;
+    double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(nblocks_), dim3(256), 0, (hipStream_t)stream, (const AdamEntry*)table, (const int*)blk_tensor,
+                       blk_off, (float)((double)lr / bc1), beta1, beta2, eps, weight_decay, (float)sqrt(bc2));
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}

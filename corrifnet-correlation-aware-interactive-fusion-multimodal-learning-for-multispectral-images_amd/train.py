@@ -1,0 +1,136 @@
+"""Training / evaluation harness around the MI355X `MMVit4`: the callers of the hot path.
+
+Restates the loops of the reference (which cannot be imported: they pull in modules that are not in the repository):
+  * `train_epoch`  - F4_TRAIN.py:41-86: `scheduler.step()` BEFORE the epoch's optimiser steps (reference quirk, F4_TRAIN.py:46),
+                     per batch `zero_grad -> model -> BCEWithLogitsLoss (on the sigmoided output) -> backward -> Adam.step`,
+                     `loss.item()` per step, `jI += Jaccard2(mask[:,0], pred[:,0]) * n`, checkpoint per epoch (F4_TRAIN.py:84).
+  * `evaluate`     - F4_TRAIN.py:181-208 / F7_TEST2.py:131-184: `model.eval()`, `torch.no_grad()`, BatchNorm running statistics.
+  * `per_image_metrics` - allJaccardResults_irem_f1_jcrd.py:201-222: Jaccard2 / F1 per image at batch 1.
+Loss, metric and the Adam update run as gfx950 kernels (ops.bce_with_logits_mean, ops.jaccard_all, corrif_adam_multi).
+"""
+import struct
+
+import torch
+
+import mmvit4
+import ops
+from corrif_hip import check, lib, stream
+
+
+class FusedAdam:
+    """torch.optim.Adam(params, lr) semantics (betas 0.9/0.999, eps 1e-8, no amsgrad; F2_MAIN.py:168-169) in ONE launch per step.
+    Parameters whose .grad is None are skipped, exactly like torch.optim.Adam (the 18 grad-less tensors of MMVit4)."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params = [p for p in params if p.requires_grad]
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.state = {}
+        self.t = 0
+        self._sig = None
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def _tables(self, live):
+        sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p in live)
+        if sig == self._sig:
+            return
+        dev = live[0].device
+        raw, bt, bo = bytearray(), [], []
+        for ti, p in enumerate(live):
+            st = self.state.get(p)
+            if st is None:
+                st = self.state[p] = (torch.zeros_like(p), torch.zeros_like(p))
+            raw += struct.pack("<QQQQq", p.data_ptr(), p.grad.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), p.numel())
+            for off in range(0, p.numel(), 1024):
+                bt.append(ti)
+                bo.append(off)
+        self._table = torch.frombuffer(raw, dtype=torch.uint8).to(dev)
+        self._bt = torch.tensor(bt, dtype=torch.int32, device=dev)
+        self._bo = torch.tensor(bo, dtype=torch.int64, device=dev)
+        self._sig = sig
+
+    @torch.no_grad()
+    def step(self):
+        live = [p for p in self.params if p.grad is not None]
+        if not live:
+            return
+        for p in live:
+            if not p.grad.is_contiguous():
+                p.grad = p.grad.contiguous()
+        self.t += 1
+        self._tables(live)
+        check(lib().corrif_adam_multi(self._table.data_ptr(), self._bt.data_ptr(), self._bo.data_ptr(), self._bt.numel(), self.lr,
+                                      self.betas[0], self.betas[1], self.eps, self.wd, self.t, stream()), "corrif_adam_multi")
+
+
+class StepLR:
+    """torch.optim.lr_scheduler.StepLR(step_size, gamma) driving FusedAdam.lr"""
+
+    def __init__(self, optim, step_size, gamma):
+        self.optim, self.step_size, self.gamma, self.base, self.epoch = optim, step_size, gamma, optim.lr, 0
+
+    def step(self):
+        self.epoch += 1
+        self.optim.lr = self.base * self.gamma ** (self.epoch // self.step_size)
+
+    def get_lr(self):
+        return [self.optim.lr]
+
+
+def train_step(model, optim, images, masks, reducer=None):
+    """F4_TRAIN.py:54-71 for one batch; returns (loss, Jaccard2 * n, n) as device tensors / ints, no host sync"""
+    (reducer or optim).zero_grad()
+    pred = model(images)
+    loss = ops.bce_with_logits_mean(pred, masks)
+    loss.backward()
+    if reducer is not None:
+        reducer.finish()
+    optim.step()
+    n = masks.shape[0] * masks.shape[-1] * masks.shape[-2]
+    jac = mmvit4.Jaccard2(masks[:, 0].reshape(n, 1), pred.detach()[:, 0].reshape(n, 1)) * n
+    return loss.detach(), jac, n
+
+
+def train_epoch(model, optim, scheduler, loader, device, reducer=None, checkpoint=None):
+    model.train()
+    scheduler.step()                                   # before the optimiser, as the reference does (F4_TRAIN.py:46)
+    losses, jI, total = [], 0.0, 0
+    for images, masks in loader:
+        loss, jac, n = train_step(model, optim, images.to(device), masks.to(device), reducer)
+        losses.append(loss.item())                     # the reference syncs here every step too (F4_TRAIN.py:64)
+        jI += jac.item()
+        total += n
+    if checkpoint:
+        torch.save(model.state_dict(), checkpoint)     # F4_TRAIN.py:84
+    return sum(losses) / max(len(losses), 1), jI / max(total, 1)
+
+
+@torch.no_grad()
+def evaluate(model, loader, device):
+    """validation / test pass: mean loss and batch-weighted soft Jaccard (F4_TRAIN.py:181-208)"""
+    model.eval()
+    losses, jI, total = [], 0.0, 0
+    for images, masks in loader:
+        images, masks = images.to(device), masks.to(device)
+        pred = model(images)
+        losses.append(ops.bce_with_logits_mean(pred, masks).item())
+        n = masks.shape[0] * masks.shape[-1] * masks.shape[-2]
+        jI += (mmvit4.Jaccard2(masks[:, 0].reshape(n, 1), pred[:, 0].reshape(n, 1)) * n).item()
+        total += n
+    return sum(losses) / max(len(losses), 1), jI / max(total, 1)
+
+
+@torch.no_grad()
+def per_image_metrics(model, images, masks):
+    """Jaccard2 and F1 per image at batch 1 (allJaccardResults_irem_f1_jcrd.py:201-222); returns two lists of floats"""
+    model.eval()
+    js, fs = [], []
+    for i in range(images.shape[0]):
+        pred = model(images[i:i + 1])
+        n = masks.shape[-1] * masks.shape[-2]
+        out = ops.jaccard_all(masks[i, 0].reshape(n, 1), pred[0, 0].reshape(n, 1))
+        js.append(out[0].item())
+        fs.append(out[2].item())
+    return js, fs

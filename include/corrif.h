@@ -289,6 +289,11 @@ size_t corrif_jaccard_workspace(int64_t n);
 int corrif_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int32_t step, void* stream);
 
+/* the same update for ALL parameters in one launch.  table: device array of {float* p; const float* g; float* m; float* v;
+ * int64_t n;} (40 bytes each); block b updates elements [blk_off[b], blk_off[b]+1024) of tensor blk_tensor[b]. */
+int corrif_adam_multi(const void* table, const int32_t* blk_tensor, const int64_t* blk_off, int32_t nblocks, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int32_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

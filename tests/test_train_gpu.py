@@ -1,0 +1,109 @@
+"""GPU: the callers of the hot path: fused Adam, the training step of F4_TRAIN.py:54-71, eval path."""
+import pytest
+import torch
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _models(seed, train):
+    import mmvit4
+    from oracle import mmvit4_oracle as O
+    ref = O.MMVit4()
+    sd = helpers.make_state_dict(ref.state_dict(), seed=seed, conv_gain=1.0)
+    ref.load_state_dict(sd)
+    hip = mmvit4.MMVit4()
+    hip.load_state_dict(sd)
+    hip = hip.to(DEV)
+    if train:
+        ref.train(); O.set_dropout(ref, False)
+        hip.train()
+        for m in hip.modules():
+            if isinstance(getattr(m, "p", None), float):
+                m.p = 0.0
+    else:
+        ref.eval(); hip.eval()
+    return ref, hip
+
+
+def test_fused_adam_matches_torch_adam_on_identical_gradients():
+    import train
+    torch.manual_seed(0)
+    shapes = [(64, 32, 1, 3, 3), (3,), (1000,), (512, 512), (1, 512, 512), (7, 5)]
+    ps = [torch.randn(s) for s in shapes]
+    ref = [p.clone().requires_grad_() for p in ps]
+    hip = [p.clone().to(DEV).requires_grad_() for p in ps]
+    extra_ref, extra_hip = torch.randn(5, requires_grad=True), torch.randn(5, device=DEV, requires_grad=True)   # never gets a grad
+    o_ref = torch.optim.Adam(ref + [extra_ref], lr=1e-3)
+    o_hip = train.FusedAdam(hip + [extra_hip], lr=1e-3)
+    before = extra_hip.detach().clone()
+    for step in range(4):
+        for r, h in zip(ref, hip):
+            g = torch.randn(r.shape) * (step + 1)
+            r.grad = g.clone()
+            h.grad = g.to(DEV)
+        o_ref.step()
+        o_hip.step()
+    torch.cuda.synchronize()
+    for r, h in zip(ref, hip):
+        assert torch.allclose(h.detach().cpu(), r.detach(), rtol=2e-6, atol=1e-7)
+    assert torch.equal(extra_hip.detach(), before)            # grad is None -> skipped, like torch.optim.Adam
+
+
+def test_train_steps_follow_the_oracle():
+    """F4_TRAIN.py:54-71 restated: step 1 must agree to fp32 noise; later steps within the Adam-amplified noise (Adam moves every
+    weight by ~lr whatever the gradient magnitude, so sign noise on near-zero gradients perturbs the trajectory at the lr level)."""
+    import train
+    from oracle import mmvit4_oracle as O
+    ref, hip = _models(21, True)
+    x, mask = helpers.make_inputs(2, 3, 32, 32)
+    o_ref = torch.optim.Adam(ref.parameters(), lr=1e-4)                   # F2_MAIN.py:168-169
+    s_ref = torch.optim.lr_scheduler.StepLR(o_ref, step_size=5, gamma=0.9)
+    o_hip = train.FusedAdam(hip.parameters(), lr=1e-4)
+    s_hip = train.StepLR(o_hip, 5, 0.9)
+    s_hip.step()
+    l_ref, l_hip, j_hip = [], [], []
+    n = 2 * 224 * 224
+    for step in range(3):
+        o_ref.zero_grad()
+        pr = ref(x)
+        lr_ = O.train_step_loss(pr, mask)
+        lr_.backward()
+        o_ref.step()
+        l_ref.append(lr_.item())
+        loss, jac, nn_ = train.train_step(hip, o_hip, x.to(DEV), mask.to(DEV))
+        l_hip.append(loss.item())
+        j_hip.append(jac.item() / nn_)
+        if step == 0:
+            jr = helpers.jaccard2_ref(mask[:, 0].reshape(n, 1), pr.detach()[:, 0].reshape(n, 1)).item()
+            assert abs(j_hip[0] - jr) < 1e-5
+    assert abs(l_hip[0] - l_ref[0]) < 2e-6
+    assert abs(l_hip[1] - l_ref[1]) < 2e-3 and abs(l_hip[2] - l_ref[2]) < 2e-3
+    assert o_hip.lr == pytest.approx(1e-4) and s_hip.get_lr() == [o_hip.lr]
+    # the 18 grad-less tensors are untouched, everything else moved
+    sd0 = helpers.make_state_dict(hip.state_dict(), seed=21, conv_gain=1.0)
+    for k, p in hip.named_parameters():
+        moved = not torch.equal(p.detach().cpu(), sd0[k])
+        assert moved != k.startswith(helpers.NOGRAD_PREFIXES), k
+
+
+def test_eval_path_and_per_image_metrics():
+    import train
+    ref, hip = _models(22, False)
+    x, mask = helpers.make_inputs(2, 3, 32, 32)
+    with torch.no_grad():
+        pr = ref(x)
+    loss, jac = train.evaluate(hip, [(x, mask)], DEV)
+    n = 2 * 224 * 224
+    jr = helpers.jaccard2_ref(mask[:, 0].reshape(n, 1), pr[:, 0].reshape(n, 1)).item()
+    assert abs(jac - jr) < 1e-5
+    assert abs(loss - torch.nn.functional.binary_cross_entropy_with_logits(pr, mask).item()) < 1e-5
+    js, fs = train.per_image_metrics(hip, x.to(DEV), mask.to(DEV))
+    for i in range(2):
+        n1 = 224 * 224
+        with torch.no_grad():
+            p1 = ref(x[i:i + 1])
+        j1 = helpers.jaccard2_ref(mask[i, 0].reshape(n1, 1), p1[0, 0].reshape(n1, 1)).item()
+        assert abs(js[i] - j1) < 1e-5 and 0.0 <= fs[i] <= 1.0
