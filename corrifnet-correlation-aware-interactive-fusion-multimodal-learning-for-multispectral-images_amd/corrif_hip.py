@@ -30,7 +30,9 @@ class Gemm(C.Structure):
     _fields_ = [("A", ptr), ("lda", i64), ("Cs", i32), ("B", ptr), ("ldb", i64), ("b_layout", i32), ("C", ptr), ("ldc", i64),
                 ("bias", ptr), ("addend", ptr), ("ld_add", i64), ("M", i32), ("N", i32), ("K", i32), ("act", i32),
                 ("Z", i32), ("Zi", i32), ("sA_o", i64), ("sA_i", i64), ("sB_o", i64), ("sB_i", i64), ("sC_o", i64), ("sC_i", i64),
-                ("g", Geom)]
+                ("g", Geom), ("ntap_sel", i32), ("tap_sel", C.c_int8 * 28),
+                ("out_map", i32), ("OD", i32), ("OH", i32), ("OW", i32), ("om_d", i32), ("om_h", i32), ("om_w", i32),
+                ("oo_d", i32), ("oo_h", i32), ("oo_w", i32)]
 
 
 class Wgrad(C.Structure):

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
             if (!p.g.is_gemm && kin) {
                 tap = q / p.Cs4;
                 c = (q - tap * p.Cs4) * 4;
+                if (p.ntap_sel) tap = p.tap_sel[tap];
                 td = (int)fdiv((uint32_t)tap, p.g.dKhw);
                 int rem = tap - td * (int)p.g.dKhw.d;
                 th = (int)fdiv((uint32_t)rem, p.g.dKw);
@@ -221,7 +222,15 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(&stg[lr * SP + cq * 4]);
                 if (row >= p.M || col >= p.N) continue;
                 v += bv;
-                float* __restrict__ dst = C + (int64_t)row * p.ldc + col;
+                int64_t orow = row;
+                if (p.out_map) {       // scatter to the strided sub-grid this GEMM's rows enumerate
+                    uint32_t n, pk;
+                    decode_row((uint32_t)row, p.g, n, pk);
+                    const int od = (int)(pk >> 20) * p.om_d + p.oo_d, oh = (int)((pk >> 10) & 1023) * p.om_h + p.oo_h,
+                              ow = (int)(pk & 1023) * p.om_w + p.oo_w;
+                    orow = (((int64_t)n * p.OD + od) * p.OH + oh) * p.OW + ow;
+                }
+                float* __restrict__ dst = C + orow * p.ldc + col;
                 if (vec_ok && col + 3 < p.N) {
                     if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + (int64_t)row * p.ld_add + col);
                     if (p.act == CORRIF_ACT_RELU) {
@@ -271,7 +280,9 @@ extern "C" int corrif_gemm_fwd(const CorrifGemm* p, void* stream) {
     if (p->b_layout == 1 && (p->N & 3)) return CORRIF_EUNSUPPORTED;
     if (p->b_layout != 0 && p->b_layout != 1) return CORRIF_EINVAL;
     if (!geom_ok(p->g)) return CORRIF_EINVAL;
-    if (!p->g.is_gemm && !scalar && p->K != p->g.kd * p->g.kh * p->g.kw * p->Cs) return CORRIF_EINVAL;
+    if (p->ntap_sel < 0 || p->ntap_sel > 28 || (p->ntap_sel && (p->g.is_gemm || scalar))) return CORRIF_EINVAL;
+    if (p->out_map && (p->g.is_gemm || p->addend || p->N > 4096 * 1024)) return CORRIF_EINVAL;
+    if (!p->g.is_gemm && !scalar && p->K != (p->ntap_sel ? p->ntap_sel : p->g.kd * p->g.kh * p->g.kw) * p->Cs) return CORRIF_EINVAL;
     if (scalar && (p->g.ntaps <= 0 || p->g.ntaps > p->g.kd * p->g.kh * p->g.kw || p->K < p->g.ntaps)) return CORRIF_EINVAL;
     if (p->Z > 65535) return CORRIF_EUNSUPPORTED;
     GemmArgs a;
@@ -280,8 +291,17 @@ extern "C" int corrif_gemm_fwd(const CorrifGemm* p, void* stream) {
     a.M = p->M; a.N = p->N; a.K = p->K; a.Cs4 = p->Cs / 4; a.act = p->act; a.b_layout = p->b_layout; a.Zi = p->Zi;
     a.sA_o = p->sA_o; a.sA_i = p->sA_i; a.sB_o = p->sB_o; a.sB_i = p->sB_i; a.sC_o = p->sC_o; a.sC_i = p->sC_i;
     a.g = make_devgeom(p->g, p->lda);
+    a.ntap_sel = p->ntap_sel;
+    for (int i = 0; i < 28; ++i) a.tap_sel[i] = p->tap_sel[i];
+    a.out_map = p->out_map; a.OD = p->OD; a.OH = p->OH; a.OW = p->OW;
+    a.om_d = p->om_d; a.om_h = p->om_h; a.om_w = p->om_w; a.oo_d = p->oo_d; a.oo_h = p->oo_h; a.oo_w = p->oo_w;
     hipStream_t s = (hipStream_t)stream;
     if (scalar) return launch_fwd<128, 64, 2, 2, 1>(a, p->Z, s);
+    if (p->ntap_sel || p->out_map) {       // parity-class data gradient: only the 32x32-MFMA tiles implement these options
+        if (p->N <= 32) return launch_fwd<256, 32, 4, 1>(a, p->Z, s);
+        if (p->N <= 64) return launch_fwd<128, 64, 2, 2>(a, p->Z, s);
+        return launch_fwd<128, 128, 2, 2>(a, p->Z, s);
+    }
     if (p->N <= 16 && !(p->N & 3) && !(p->ldc & 3) && !((uintptr_t)p->C & 15) && !(p->sC_o & 3) && !(p->sC_i & 3) &&
         (!p->addend || (!(p->ld_add & 3) && !((uintptr_t)p->addend & 15))))
         return launch_smalln_fwd(a, p->Z, s);

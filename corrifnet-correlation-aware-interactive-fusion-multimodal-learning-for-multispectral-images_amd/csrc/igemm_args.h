@@ -11,6 +11,8 @@ struct GemmArgs {
     int M, N, K, Cs4, act, b_layout, Zi;
     int64_t sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
     DevGeom g;
+    int ntap_sel; int8_t tap_sel[28];
+    int out_map, OD, OH, OW, om_d, om_h, om_w, oo_d, oo_h, oo_w;
 };
 
 

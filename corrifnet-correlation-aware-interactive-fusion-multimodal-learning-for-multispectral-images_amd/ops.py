@@ -55,8 +55,15 @@ def _ws(nbytes, dev):
 
 
 def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, addend=None, ld_add=0, act=ACT_NONE,
-         Z=1, Zi=1, sA=(0, 0), sB=(0, 0), sC=(0, 0)):
+         Z=1, Zi=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), taps=None, out_map=None):
     g = H.Gemm()
+    if taps is not None:
+        g.ntap_sel = len(taps)
+        for i, t in enumerate(taps):
+            g.tap_sel[i] = t
+    if out_map is not None:
+        g.out_map = 1
+        (g.OD, g.OH, g.OW), (g.om_d, g.om_h, g.om_w), (g.oo_d, g.oo_h, g.oo_w) = out_map
     g.A, g.lda, g.Cs = A, lda, Cs
     g.B, g.ldb, g.b_layout = Bm, ldb, b_layout
     g.C, g.ldc = Cout, ldc
@@ -131,6 +138,49 @@ def _patch_cc(k, stride, pad, Ci, Co):
     if k != (3, 3, 3) or stride != (1, 1, 1) or pad != (1, 1, 1):
         return 0
     return lib().corrif_conv3_patch_cc(Ci, Co)
+
+
+def _dgrad_parity_classes(gy, ldg, wd, gx, B, Sin, Sout, k, stride, pad, Ci, Co):
+    """Data gradient of a strided convolution without multiplying zeros.  Input voxel i receives tap t only if (i + pad - t) is a
+    multiple of the stride, so the input grid splits into stride^3 parity classes, each with its own small tap subset
+    (3x3 / stride 2: 1, 2, 2 and 4 taps; 1x1 / stride 2: one class with one tap, three classes with none = zeros).  One GEMM per
+    class over that class's sub-grid, K = |taps| * Co, rows scattered back with the kernel's output row map.
+    wd: [T*Co, Ci] data-gradient weights (tap-major).  gx: [B, Di, Hi, Wi, Ci] is fully written."""
+    kd, kh, kw = k
+    covered = True
+    launches = []
+    for pd_ in range(stride[0]):
+        for ph_ in range(stride[1]):
+            for pw_ in range(stride[2]):
+                par = (pd_, ph_, pw_)
+                R = tuple((Sin[a] - par[a] + stride[a] - 1) // stride[a] for a in range(3))
+                if min(R) <= 0:
+                    continue
+                taps = [(td * kh + th) * kw + tw for td in range(kd) for th in range(kh) for tw in range(kw)
+                        if (par[0] + pad[0] - td) % stride[0] == 0 and (par[1] + pad[1] - th) % stride[1] == 0
+                        and (par[2] + pad[2] - tw) % stride[2] == 0]
+                if not taps:
+                    covered = False
+                    continue
+                launches.append((par, R, taps))
+    if not covered:
+        gx.zero_()                                  # classes no tap can reach (1x1 stride-2: 3 of 4) keep exact zeros
+    for par, R, taps in launches:
+        wc = torch.empty((len(taps) * Co, Ci), dtype=torch.float32, device=gx.device)
+        for j, t in enumerate(taps):                # gather this class's tap blocks [Co][Ci] of the tap-major weight matrix
+            check(lib().corrif_copy2d(wd.data_ptr() + 4 * t * Co * Ci, Ci, wc.data_ptr() + 4 * j * Co * Ci, Ci, Co, Ci, 0, stream()),
+                  "corrif_copy2d")
+        g = H.Geom()
+        g.is_gemm = 0
+        g.Rd, g.Rh, g.Rw = R
+        g.Sd, g.Sh, g.Sw = Sout
+        g.kd, g.kh, g.kw = k
+        g.mul_d, g.mul_h, g.mul_w = stride
+        g.off_d, g.off_h, g.off_w = (par[0] + pad[0], par[1] + pad[1], par[2] + pad[2])
+        g.div_d, g.div_h, g.div_w = stride
+        g.dir, g.clamp, g.ntaps = -1, 0, kd * kh * kw
+        gemm(P(gy), ldg, P(wc), Ci, 1, P(gx), Ci, B * R[0] * R[1] * R[2], Ci, len(taps) * Co, Co, g, taps=taps,
+             out_map=(Sin, stride, par))
 
 
 def _out_size(i, k, s, p):
@@ -216,6 +266,8 @@ class ConvFn(Function):
                     geom = H.conv_geom(Rg, (Do, Ho, Wo), (kd, kh, kw), (1, 1, 1), (0, 0, 0), transposed=True)
                     gemm(P(gy), ldg, P(wd), Ci, 1, P(gxp), Ci, B * Rg[0] * Rg[1] * Rg[2], Ci, T * Co, Co, geom)
                     check(lib().corrif_pad_fold(P(gxp), P(gx), Ci, B, Di, Hi, Wi, Ci, stream()), "corrif_pad_fold")
+                elif stride != (1, 1, 1):
+                    _dgrad_parity_classes(gy, ldg, wd, gx, B, (Di, Hi, Wi), (Do, Ho, Wo), (kd, kh, kw), stride, pad, Ci, Co)
                 else:
                     geom = H.conv_geom((Di, Hi, Wi), (Do, Ho, Wo), (kd, kh, kw), stride, pad, transposed=True)
                     gemm(P(gy), ldg, P(wd), Ci, 1, P(gx), Ci, Min, Ci, T * Co, Co, geom)

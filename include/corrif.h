@@ -83,6 +83,13 @@ typedef struct CorrifGemm {
     int32_t Z, Zi;                                /* batch count (>=1), inner batch extent   */
     int64_t sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
     CorrifGeom g;
+    /* optional tap subset: K enumerates (tap_sel[0..ntap_sel), channel) instead of all kd*kh*kw taps (ntap_sel = 0: all).
+     * Used by the parity-class data gradient of stride-2 convolutions, which only visits the taps that can be non-zero. */
+    int32_t ntap_sel; int8_t tap_sel[28];
+    /* optional output row map: GEMM row r = (n, rd, rh, rw) on the g.R* grid is stored at voxel
+     * (n, rd*om_d + oo_d, rh*om_h + oo_h, rw*om_w + oo_w) of an OD x OH x OW grid (out_map = 0: row r itself).
+     * Requires is_gemm = 0.  bias/addend are not combined with it. */
+    int32_t out_map, OD, OH, OW, om_d, om_h, om_w, oo_d, oo_h, oo_w;
 } CorrifGemm;
 int corrif_gemm_fwd(const CorrifGemm* p, void* stream);
 

@@ -49,8 +49,9 @@ def test_ctypes_struct_layout_matches_header(built):
 #include <stddef.h>
 #include "corrif.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(CorrifGeom), offsetof(CorrifGeom, src_batch_pitch), sizeof(CorrifGemm),
-         offsetof(CorrifGemm, bias), offsetof(CorrifGemm, g), sizeof(CorrifWgrad), offsetof(CorrifWgrad, ws), offsetof(CorrifWgrad, g));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(CorrifGeom), offsetof(CorrifGeom, src_batch_pitch), sizeof(CorrifGemm),
+         offsetof(CorrifGemm, bias), offsetof(CorrifGemm, g), sizeof(CorrifWgrad), offsetof(CorrifWgrad, ws), offsetof(CorrifWgrad, g),
+         offsetof(CorrifGemm, tap_sel), offsetof(CorrifGemm, oo_w), sizeof(CorrifConv3Patch));
   return 0; }
 '''
     d = os.path.join(helpers.PKG, "build")
@@ -61,7 +62,8 @@ int main(void) {
     subprocess.check_call(["gcc", "-I", os.path.join(helpers.ROOT, "include"), c, "-o", exe])
     got = [int(v) for v in subprocess.check_output([exe]).split()]
     want = [ctypes.sizeof(H.Geom), H.Geom.src_batch_pitch.offset, ctypes.sizeof(H.Gemm), H.Gemm.bias.offset, H.Gemm.g.offset,
-            ctypes.sizeof(H.Wgrad), H.Wgrad.ws.offset, H.Wgrad.g.offset]
+            ctypes.sizeof(H.Wgrad), H.Wgrad.ws.offset, H.Wgrad.g.offset, H.Gemm.tap_sel.offset, H.Gemm.oo_w.offset,
+            ctypes.sizeof(H.Conv3Patch)]
     assert got == want
 
 
