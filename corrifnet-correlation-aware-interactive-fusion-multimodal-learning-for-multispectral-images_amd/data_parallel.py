@@ -62,20 +62,30 @@ class GradAllReducer:
             p.grad = v               # gradient now lives inside the bucket (autograd accumulates in place)
             views.append(v)
             o += p.numel()
-        return {"params": params, "flat": flat, "ready": 0, "work": None}
+        return {"params": params, "flat": flat, "ready": 0, "work": None, "events": []}
 
     # ---------------------------------------------------------------- hooks / reduction
     def _on_grad(self, p):
         b = self.buckets[self._index[p]]
         b["ready"] += 1
+        if self._stream is not None:
+            # gradients of one bucket may be accumulated on different streams (the model runs its three modality branches
+            # on three streams): remember where each one was produced
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            b["events"].append(ev)
         if b["ready"] == len(b["params"]):
             self._launch(b)
 
     def _launch(self, b):
         if self.world == 1:
+            b["events"] = []
             return
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())
+            for ev in b["events"]:
+                self._stream.wait_event(ev)
+            b["events"] = []
             with torch.cuda.stream(self._stream):
                 b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
@@ -91,6 +101,7 @@ class GradAllReducer:
             b["flat"].zero_()
             b["ready"] = 0
             b["work"] = None
+            b["events"] = []
 
     def finish(self):
         """call after backward(): waits for / issues the all-reduces and averages.  After it returns every rank holds the
