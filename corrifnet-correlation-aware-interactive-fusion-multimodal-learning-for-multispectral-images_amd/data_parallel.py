@@ -15,9 +15,10 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, model, bucket_bytes=64 << 20, process_group=None, overlap=True):
+    def __init__(self, model, bucket_bytes=64 << 20, process_group=None, overlap=True, force_collective=False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.force = force_collective and dist.is_initialized()      # run the collectives even with one rank (single-GPU rehearsal)
         self.overlap = overlap
         self._limit = max(1, bucket_bytes // 4)
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -78,7 +79,7 @@ class GradAllReducer:
             self._launch(b)
 
     def _launch(self, b):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             b["events"] = []
             return
         if self._stream is not None:
@@ -110,13 +111,13 @@ class GradAllReducer:
         if first:
             self._build()
         for b in self.buckets:
-            if self.world > 1 and (b["work"] is None):
+            if (self.world > 1 or self.force) and (b["work"] is None):
                 self._launch(b)      # first step (hooks not yet installed) or overlap disabled
         for b in self.buckets:
             if b["work"] is not None:
                 b["work"].wait()
                 b["work"] = None
-            if self.world > 1:
+            if self.world > 1 or self.force:
                 if self._stream is not None:
                     torch.cuda.current_stream().wait_stream(self._stream)
                 b["flat"].mul_(1.0 / self.world)

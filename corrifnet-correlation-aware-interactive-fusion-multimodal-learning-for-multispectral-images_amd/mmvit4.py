@@ -241,6 +241,8 @@ class Decoder_fuse(nn.Module):
             if side is None:
                 side = self._side = torch.cuda.Stream(device=dev)
             side.wait_stream(cur)
+            for t in (x1, x2, x3, x4) + tuple(cats):      # allocated on the caller's stream, used (and saved) on the side stream
+                t.record_stream(side)
             events = []
             with torch.cuda.stream(side):
                 for l, (rfm, skip, n, _, _, _) in enumerate(stages):
@@ -418,6 +420,11 @@ class MMVit4(nn.Module):
             for i, m in enumerate(_MODS):
                 st = self._streams[i]
                 st.wait_stream(cur)
+                # tensors allocated on the caller's stream that this branch reads / writes (also from its saved-for-backward
+                # state): tell the caching allocator, or their memory could be re-used while the branch stream still needs it
+                x.record_stream(st)
+                for c in cats:
+                    c.record_stream(st)
                 with torch.cuda.stream(st):
                     branch(i, m)
             for st in self._streams:

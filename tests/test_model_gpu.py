@@ -189,9 +189,28 @@ def test_module_surface():
 
 def test_determinism():
     case = dict(B=2, D=3, H=32, W=32, mode="train_nodrop", conv_gain=1.0, wseed=3)
-    _, p1, _, l1, _ = run_hip(case)
+    m1, p1, _, l1, _ = run_hip(case)
     m2, p2, _, l2, _ = run_hip(case)
     assert torch.equal(p1, p2) and l1.item() == l2.item()                   # no atomics anywhere: bit-identical reruns
+    g2 = dict(m2.named_parameters())
+    for k, p in m1.named_parameters():                                      # ... of every gradient too (two live models, both
+        if p.grad is not None:                                              # on their own branch / side streams: this also
+            assert torch.equal(p.grad, g2[k].grad), k                       # guards the cross-stream allocator hazards)
+    # and the concurrent schedule equals the serial one bit for bit
+    import mmvit4
+    m3, _ = build_hip(case)
+    m3.concurrent_branches = False
+    m3.decoder_fuse.concurrent_skips = False
+    import ops
+    x, mask = helpers.make_inputs(case["B"], case["D"], case["H"], case["W"])
+    p3 = m3(x.to(DEV))
+    ops.bce_with_logits_mean(p3, mask.to(DEV)).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(p1, p3)
+    g3 = dict(m3.named_parameters())
+    for k, p in m1.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, g3[k].grad), k
 
 
 def test_dropout_train_mode_runs_and_is_unbiased():

@@ -107,3 +107,39 @@ def test_eval_path_and_per_image_metrics():
             p1 = ref(x[i:i + 1])
         j1 = helpers.jaccard2_ref(mask[i, 0].reshape(n1, 1), p1[0, 0].reshape(n1, 1)).item()
         assert abs(js[i] - j1) < 1e-5 and 0.0 <= fs[i] <= 1.0
+
+
+def test_reducer_rccl_path_single_rank():
+    """the N > 1 code path (bucket views, post-accumulate hooks on three branch streams, async RCCL all-reduce on a side stream)
+    rehearsed with ONE rank on the GPU: gradients must equal the plain backward, step after step."""
+    import os
+    import torch.distributed as dist
+    import ops
+    from data_parallel import GradAllReducer, broadcast_module_state
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        _, hip = _models(23, True)
+        _, hip2 = _models(23, True)
+        broadcast_module_state(hip)
+        red = GradAllReducer(hip, bucket_bytes=8 << 20, force_collective=True)
+        x, mask = helpers.make_inputs(2, 3, 32, 32)
+        for step in range(3):
+            red.zero_grad()
+            ops.bce_with_logits_mean(hip(x.to(DEV)), mask.to(DEV)).backward()
+            red.finish()
+            for p in hip2.parameters():
+                p.grad = None
+            ops.bce_with_logits_mean(hip2(x.to(DEV)), mask.to(DEV)).backward()
+            torch.cuda.synchronize()
+            p2 = dict(hip2.named_parameters())
+            for k, p in hip.named_parameters():
+                if p2[k].grad is None:
+                    assert p.grad is None or float(p.grad.abs().sum()) == 0.0, k
+                else:
+                    assert torch.equal(p.grad, p2[k].grad), (step, k)
+        assert len(red.buckets) > 5 and red.communicated_elements() == 85343883      # the 18 grad-less tensors never travel
+    finally:
+        dist.destroy_process_group()
