@@ -155,6 +155,24 @@ def test_full_gradient_against_oracle():
         assert e_hip <= max(3 * e_ref, 1e-4), (k, e_hip, e_ref)
 
 
+@pytest.mark.parametrize("B,D,HW", [(1, 8, 256), (1, 12, 512), (3, 5, 100)])
+def test_other_baseline_configs_forward(B, D, HW):
+    """BASELINE configs[2] / [4] geometry (8 bands 256^2, 12 bands 512^2) and an odd size, eval mode, against the CPU oracle.
+    Eval-mode fp32 noise of the reference itself is ~2e-5 on the sigmoid output (fixtures); bound 1.5e-4."""
+    from oracle import mmvit4_oracle as O
+    case = dict(B=B, D=D, H=HW, W=HW, mode="eval", conv_gain=1.0, wseed=31)
+    model, sd = build_hip(case)
+    x, _ = helpers.make_inputs(B, D, HW, HW)
+    with torch.no_grad():
+        pg = model(x.to(DEV))
+        ref = O.MMVit4()
+        ref.load_state_dict(sd)
+        ref.eval()
+        pr = ref(x)
+    assert pg.shape == (B, 3, 1, 224, 224)
+    assert (pg.cpu() - pr).abs().max().item() < 1.5e-4
+
+
 def test_module_surface():
     """the calls F2_MAIN / F4_TRAIN make on the model."""
     import mmvit4
