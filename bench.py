@@ -208,11 +208,20 @@ def main():
                                       "(BASELINE configs[1])" % (args.bands, args.size, args.size, B),
                           "global_batch": world * B, "parallelism": "dp%d" % world, "loss": float(loss.item()),
                           "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2)}}
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_mfma_traffic.json")
+        if os.path.exists(tpath) and B == 32 and args.bands == 4 and args.size == 224:
+            try:      # HBM bytes of the MFMA kernel family for ONE step of this workload, from committed rocprofv3 PMC passes
+                traffic = float(json.load(open(tpath))["mfma_family_hbm_bytes_per_step"])
+            except Exception:
+                traffic = None
         if timer:
             fl, ms, n = timer.summary()
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                               "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                               "traffic_note": "HBM bytes per step of the same launches (sum over the MFMA family), rocprofv3 FETCH_SIZE x2 + "
+                                               "WRITE_SIZE from separate --pmc passes (profiles/r01_mfma_traffic.json); algorithmic = 243 GB",
                                "kernel": "gemm_fwd_kernel+wgrad_kernel+conv3_patch_kernel (fp32 MFMA implicit GEMM / patch conv)",
                                "launches_per_step": n // max(kt_steps, 1), "mfma_ms_per_step": round(ms / max(kt_steps, 1), 3),
                                "algorithmic_gflop_per_step": round(fl / max(kt_steps, 1) / 1e9, 1),
