@@ -32,7 +32,8 @@ class Gemm(C.Structure):
                 ("Z", i32), ("Zi", i32), ("sA_o", i64), ("sA_i", i64), ("sB_o", i64), ("sB_i", i64), ("sC_o", i64), ("sC_i", i64),
                 ("g", Geom), ("ntap_sel", i32), ("tap_sel", C.c_int8 * 28),
                 ("out_map", i32), ("OD", i32), ("OH", i32), ("OW", i32), ("om_d", i32), ("om_h", i32), ("om_w", i32),
-                ("oo_d", i32), ("oo_h", i32), ("oo_w", i32)]
+                ("oo_d", i32), ("oo_h", i32), ("oo_w", i32),
+                ("stats_part", ptr), ("stats_rows_per_group", i64), ("stats_relu", i32)]
 
 
 class Wgrad(C.Structure):
@@ -74,6 +75,7 @@ _SIGS = {
     "corrif_col_sum_workspace": (C.c_size_t, [i64, i32]),
     "corrif_weight_repack": (i32, [ptr, ptr, i32, i32, i32, i32, i64, ptr]),
     "corrif_norm_stats": (i32, [ptr, i64, i64, i32, i32, i32, f32, ptr, ptr, ptr, ptr, f32, ptr, ptr]),
+    "corrif_norm_stats_finalize": (i32, [ptr, i32, i32, i32, i64, f32, ptr, ptr, ptr, ptr, f32, ptr]),
     "corrif_norm_eval_rstd": (i32, [ptr, f32, ptr, i32, ptr]),
     "corrif_norm_apply": (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, i64, i64, i32, i32, i32, ptr]),
     "corrif_norm_bwd": (i32, [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, ptr, i64, i32, i32, i32, i32, ptr, ptr]),

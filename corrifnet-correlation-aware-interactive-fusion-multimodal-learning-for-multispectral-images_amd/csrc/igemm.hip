@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
             for (int e = 0; e < 4; ++e)
                 if (col + e < p.N) bv[e] = p.bias[col + e];
         }
+        double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};      // fused norm statistics of this lane's 4 columns (double: no cancellation loss)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -222,6 +223,14 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(&stg[lr * SP + cq * 4]);
                 if (row >= p.M || col >= p.N) continue;
                 v += bv;
+                if (p.stats_part) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const double sv = (double)(p.stats_relu ? fmaxf(v[e], 0.f) : v[e]);
+                        ssum[e] += sv;
+                        ssq[e] += sv * sv;
+                    }
+                }
                 int64_t orow = row;
                 if (p.out_map) {       // scatter to the strided sub-grid this GEMM's rows enumerate
                     uint32_t n, pk;
@@ -252,6 +261,23 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
                         dst[e] = x;
                     }
                 }
+            }
+        }
+        if (p.stats_part) {       // TM == 2: the wave's rows are one 64-row block; sum over the RPP lanes that share a column chunk
+#pragma unroll
+            for (int off = CQ; off < 64; off <<= 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ssum[e] += __shfl_xor(ssum[e], off); ssq[e] += __shfl_xor(ssq[e], off); }
+            const int row0 = m0 + wm * TM * 32;
+            if (lane < CQ && row0 < p.M) {
+                const int g = row0 / p.stats_rpg, chunk = (row0 - g * p.stats_rpg) >> 6;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < p.N) {
+                        double* o = p.stats_part + (((int64_t)g * p.N + col + e) * p.stats_chunks + chunk) * 2;
+                        o[0] = ssum[e];
+                        o[1] = ssq[e];
+                    }
             }
         }
     }
@@ -293,6 +319,14 @@ extern "C" int corrif_gemm_fwd(const CorrifGemm* p, void* stream) {
     a.g = make_devgeom(p->g, p->lda);
     a.ntap_sel = p->ntap_sel;
     for (int i = 0; i < 28; ++i) a.tap_sel[i] = p->tap_sel[i];
+    a.stats_part = p->stats_part; a.stats_relu = p->stats_relu; a.stats_rpg = 1; a.stats_chunks = 1;
+    if (p->stats_part) {
+        if (p->Z != 1 || p->stats_rows_per_group <= 0 || p->stats_rows_per_group > p->M || (p->M % p->stats_rows_per_group)) return CORRIF_EINVAL;
+        if (p->stats_rows_per_group != p->M && (p->stats_rows_per_group & 63)) return CORRIF_EUNSUPPORTED;
+        if (scalar || p->out_map || p->N <= 16) return CORRIF_EUNSUPPORTED;     // only the TM = 2 tiles of gemm_fwd_kernel produce them
+        a.stats_rpg = (int)p->stats_rows_per_group;
+        a.stats_chunks = (int)((p->stats_rows_per_group + 63) / 64);
+    }
     a.out_map = p->out_map; a.OD = p->OD; a.OH = p->OH; a.OW = p->OW;
     a.om_d = p->om_d; a.om_h = p->om_h; a.om_w = p->om_w; a.oo_d = p->oo_d; a.oo_h = p->oo_h; a.oo_w = p->oo_w;
     hipStream_t s = (hipStream_t)stream;
@@ -309,12 +343,13 @@ extern "C" int corrif_gemm_fwd(const CorrifGemm* p, void* stream) {
     // 128-wide tiles measured faster than 64x64 even at ~1.5 workgroups per CU (e4: M=25088,N=256,K=2304: 70 vs 56 TF/s);
     // shrink only when the grid could not even cover the 256 CUs once.
     auto tiles = [&](int bm, int bn) { return (int64_t)((p->M + bm - 1) / bm) * ((p->N + bn - 1) / bn) * p->Z; };
+    const bool st = p->stats_part != nullptr;       // fused statistics need 64-row wave blocks (TM = 2)
     if (p->N <= 64) {
-        if (tiles(128, 64) >= 192) return launch_fwd<128, 64, 2, 2>(a, p->Z, s);
+        if (st || tiles(128, 64) >= 192) return launch_fwd<128, 64, 2, 2>(a, p->Z, s);
         return launch_fwd<64, 64, 2, 2>(a, p->Z, s);
     }
     if (tiles(128, 128) >= 192) return launch_fwd<128, 128, 2, 2>(a, p->Z, s);
-    if (tiles(128, 64) >= 192) return launch_fwd<128, 64, 2, 2>(a, p->Z, s);
+    if (st || tiles(128, 64) >= 192) return launch_fwd<128, 64, 2, 2>(a, p->Z, s);
     return launch_fwd<64, 64, 2, 2>(a, p->Z, s);
 }
 

@@ -13,6 +13,7 @@ struct GemmArgs {
     DevGeom g;
     int ntap_sel; int8_t tap_sel[28];
     int out_map, OD, OH, OW, om_d, om_h, om_w, oo_d, oo_h, oo_w;
+    double* stats_part; int stats_relu; int stats_rpg, stats_chunks;
 };
 
 

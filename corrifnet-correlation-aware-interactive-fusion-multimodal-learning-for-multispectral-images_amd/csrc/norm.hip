@@ -284,6 +284,16 @@ extern "C" int corrif_norm_stats(const float* x, int64_t ldx, int64_t rows_per_g
     return CORRIF_OK;
 }
 
+extern "C" int corrif_norm_stats_finalize(const double* part, int32_t chunks, int32_t G, int32_t C, int64_t rows_per_group, float eps, float* mean,
+                                          float* rstd, float* running_mean, float* running_var, float momentum, void* stream) {
+    if (!part || !mean || !rstd || chunks <= 0 || !norm_args_ok(rows_per_group, G, C)) return CORRIF_EINVAL;
+    if (running_mean && (G != 1 || !running_var)) return CORRIF_EINVAL;
+    hipLaunchKernelGGL(norm_stats_final_kernel, dim3((G * C + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, (int)chunks, (int)G, (int)C,
+                       rows_per_group, eps, mean, rstd, running_mean, running_var, momentum);
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}
+
 extern "C" int corrif_norm_eval_rstd(const float* running_var, float eps, float* rstd, int32_t C, void* stream) {
     if (!running_var || !rstd || C <= 0) return CORRIF_EINVAL;
     hipLaunchKernelGGL(eval_rstd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, running_var, eps, rstd, (int)C);

@@ -46,8 +46,8 @@ class Conv3dP(nn.Module):
         else:
             self.register_parameter("bias", None)
 
-    def forward(self, x, out=None):
-        return ops.conv3d(x, self.weight, self.bias, self.stride, self.pad, self.replicate, out)
+    def forward(self, x, out=None, stats=None):
+        return ops.conv3d(x, self.weight, self.bias, self.stride, self.pad, self.replicate, out, stats=stats)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%s, stride=%s, padding=%s%s%s" % (
@@ -65,11 +65,11 @@ class BatchNorm3dP(nn.Module):
         self.register_buffer("running_var", torch.ones(c))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x, residual=None, relu_in=False, relu_out=False, out=None):
+    def forward(self, x, residual=None, relu_in=False, relu_out=False, out=None, pre=None):
         if self.training:
             self.num_batches_tracked += 1
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, residual, relu_in, relu_out,
-                              self.training, self.momentum, self.eps, out)
+                              self.training, self.momentum, self.eps, out, pre)
 
     def extra_repr(self):
         return "%d, eps=%g, momentum=%g" % (self.weight.numel(), self.eps, self.momentum)
@@ -78,8 +78,8 @@ class BatchNorm3dP(nn.Module):
 class InstanceNorm3dP(nn.Module):
     """nn.InstanceNorm3d(affine=False, track_running_stats=False): no parameters, no buffers (mmvit4.py:24)."""
 
-    def forward(self, x, out=None):           # applied AFTER the ReLU, fused with it (mmvit4.py:41-45)
-        return ops.relu_instnorm(x, 1e-5, out)
+    def forward(self, x, out=None, pre=None):           # applied AFTER the ReLU, fused with it (mmvit4.py:41-45)
+        return ops.relu_instnorm(x, 1e-5, out, pre)
 
 
 class general_conv3d_prenorm(nn.Module):
@@ -91,7 +91,8 @@ class general_conv3d_prenorm(nn.Module):
         self.norm = InstanceNorm3dP()
 
     def forward(self, x, out=None):
-        return self.norm(self.conv(x), out)
+        st = {"G": x.shape[0], "relu": True}            # the conv's epilogue also produces the InstanceNorm statistics partials
+        return self.norm(self.conv(x, stats=st), out, pre=st)
 
 
 class fusion_prenorm(nn.Module):
@@ -118,7 +119,8 @@ class EarlyFusionBlock(nn.Module):
         self.norm = InstanceNorm3dP()
 
     def forward(self, cat):
-        return self.norm(self.conv(cat))
+        st = {"G": cat.shape[0], "relu": True}
+        return self.norm(self.conv(cat, stats=st), pre=st)
 
 
 class Bottleneck3D(nn.Module):
@@ -136,10 +138,19 @@ class Bottleneck3D(nn.Module):
         self.downsample = nn.Sequential(Conv3dP(cin, cout, 1, (1, stride, stride), 0, False), BatchNorm3dP(cout)) if down else None
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
-        y = self.bn1(self.conv1(x), relu_out=True)
-        y = self.bn2(self.conv2(y), relu_out=True)
-        return self.bn3(self.conv3(y), residual=idt, relu_out=True)
+        train = self.training
+
+        def st():                                   # BatchNorm batch statistics come out of the producing GEMM's epilogue
+            return {"G": 1, "relu": False} if train else None
+
+        idt = x
+        if self.downsample is not None:
+            s0 = st()
+            idt = self.downsample[1](self.downsample[0](x, stats=s0), pre=s0)
+        s1, s2, s3 = st(), st(), st()
+        y = self.bn1(self.conv1(x, stats=s1), relu_out=True, pre=s1)
+        y = self.bn2(self.conv2(y, stats=s2), relu_out=True, pre=s2)
+        return self.bn3(self.conv3(y, stats=s3), residual=idt, relu_out=True, pre=s3)
 
 
 def _res_layer(cin, width, n, stride):

@@ -55,8 +55,10 @@ def _ws(nbytes, dev):
 
 
 def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, addend=None, ld_add=0, act=ACT_NONE,
-         Z=1, Zi=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), taps=None, out_map=None):
+         Z=1, Zi=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), taps=None, out_map=None, stats=None):
     g = H.Gemm()
+    if stats is not None:
+        g.stats_part, g.stats_rows_per_group, g.stats_relu = stats
     if taps is not None:
         g.ntap_sel = len(taps)
         for i, t in enumerate(taps):
@@ -192,7 +194,7 @@ class ConvFn(Function):
     """nn.Conv3d on channels-last activations.  weight stays in the reference (O,I,kd,kh,kw) layout."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, replicate, out, act):
+    def forward(ctx, x, weight, bias, stride, pad, replicate, out, act, stats_req):
         Co, Ci, kd, kh, kw = weight.shape
         T = kd * kh * kw
         stem = Ci == 1
@@ -226,7 +228,17 @@ class ConvFn(Function):
         else:
             wp = weight if T == 1 else repack(weight, (Co, T * Ci), Co, Ci, T, 0, T * Ci)
             geom = H.gemm_geom() if is_gemm else H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad, clamp=replicate)
-            gemm(P(x), lda, P(wp), T * Ci, 0, P(y), ldc, M, Co, T * Ci, Ci, geom, bias=P(bias) if bias is not None else None, act=act)
+            st = None
+            if stats_req is not None and Co > 16 and act == ACT_NONE:
+                G = stats_req["G"]
+                rpg = M // G
+                if M % G == 0 and (G == 1 or rpg % 64 == 0):
+                    chunks = (rpg + 63) // 64          # sum / sum-of-squares partials for the norm that follows, from the epilogue
+                    part = torch.empty(G * Co * chunks * 2, dtype=torch.float64, device=x.device)
+                    st = (part.data_ptr(), rpg, 1 if stats_req["relu"] else 0)
+                    stats_req["part"], stats_req["chunks"], stats_req["rpg"] = part, chunks, rpg
+            gemm(P(x), lda, P(wp), T * Ci, 0, P(y), ldc, M, Co, T * Ci, Ci, geom, bias=P(bias) if bias is not None else None, act=act,
+                 stats=st)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, replicate, bias is not None, (B, Di, Hi, Wi), (Do, Ho, Wo), stem, is_gemm, lda, batch_pitch)
         return out
@@ -277,7 +289,7 @@ class ConvFn(Function):
             gb = torch.empty(Co, dtype=torch.float32, device=dev) if has_bias else None
             ws = _ws(lib().corrif_conv1x1_small_workspace(M, Ci, Co), dev)
             check(lib().corrif_conv1x1_small_wgrad(P(x), lda, P(gy), ldg, P(gw), P(gb), P(ws), M, Ci, Co, stream()), "corrif_conv1x1_small_wgrad")
-            return gx, gw, gb, None, None, None, None, None
+            return gx, gw, gb, None, None, None, None, None, None
         if ctx.needs_input_grad[1]:
             if stem:
                 Kp = (T + 3) // 4 * 4
@@ -299,11 +311,13 @@ class ConvFn(Function):
                 gw = repack(gwp, weight.shape, Co, Ci, T, 2, T * Ci)
         if has_bias and ctx.needs_input_grad[2]:
             gb = col_sum(gy, M, ldg, Co)
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
-def conv3d(x, weight, bias=None, stride=(1, 1, 1), pad=(0, 0, 0), replicate=False, out=None, act=ACT_NONE):
-    return ConvFn.apply(x, weight, bias, tuple(stride), tuple(pad), bool(replicate), out, act)
+def conv3d(x, weight, bias=None, stride=(1, 1, 1), pad=(0, 0, 0), replicate=False, out=None, act=ACT_NONE, stats=None):
+    """stats: None, or a dict {"G": groups, "relu": bool}: ask the GEMM epilogue for the statistics partials of the norm that follows;
+    on success the dict gains "part" / "chunks" / "rpg" (pass it to batch_norm / relu_instnorm as `pre`)."""
+    return ConvFn.apply(x, weight, bias, tuple(stride), tuple(pad), bool(replicate), out, act, stats)
 
 
 # --------------------------------------------------------------------------------------- linear
@@ -349,16 +363,20 @@ class BatchNormFn(Function):
     """y = act_out(gamma * (x' - mean) * rstd + beta + residual), x' = relu(x) if relu_in.  Statistics over all rows."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, flags, training, momentum, eps, out):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, flags, training, momentum, eps, out, pre):
         x, rows, ldx = rows_view(x)
         C = x.shape[-1]
         dev = x.device
         if training:
             mean = torch.empty(C, dtype=torch.float32, device=dev)
             rstd = torch.empty(C, dtype=torch.float32, device=dev)
-            ws = _norm_ws(rows, 1, C, dev)
-            check(lib().corrif_norm_stats(P(x), ldx, rows, 1, C, flags, eps, P(mean), P(rstd), P(running_mean), P(running_var),
-                                          momentum, P(ws), stream()), "corrif_norm_stats")
+            if pre is not None and "part" in pre and pre["rpg"] == rows and pre["G"] == 1 and bool(pre["relu"]) == bool(flags & NORM_RELU_IN):
+                check(lib().corrif_norm_stats_finalize(P(pre["part"]), pre["chunks"], 1, C, rows, eps, P(mean), P(rstd), P(running_mean),
+                                                       P(running_var), momentum, stream()), "corrif_norm_stats_finalize")
+            else:
+                ws = _norm_ws(rows, 1, C, dev)
+                check(lib().corrif_norm_stats(P(x), ldx, rows, 1, C, flags, eps, P(mean), P(rstd), P(running_mean), P(running_var),
+                                              momentum, P(ws), stream()), "corrif_norm_stats")
         else:
             mean = running_mean
             rstd = torch.empty(C, dtype=torch.float32, device=dev)
@@ -394,29 +412,33 @@ class BatchNormFn(Function):
         ws = _norm_ws(rows, 1, C, dev)
         check(lib().corrif_norm_bwd(P(gy), ldg, P(y), ldy, P(x), ldx, P(mean), P(rstd), P(gamma), P(gx), C, P(gres), C,
                                     P(ggamma), P(gbeta), rows, 1, C, flags, 1 if frozen else 0, P(ws), stream()), "corrif_norm_bwd")
-        return gx, ggamma, gbeta, None, None, gres, None, None, None, None, None
+        return gx, ggamma, gbeta, None, None, gres, None, None, None, None, None, None
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, residual=None, relu_in=False, relu_out=False, training=True,
-               momentum=0.1, eps=1e-5, out=None):
+               momentum=0.1, eps=1e-5, out=None, pre=None):
     flags = (NORM_RELU_IN if relu_in else 0) | (NORM_RELU_OUT if relu_out else 0)
-    return BatchNormFn.apply(x, gamma, beta, running_mean, running_var, residual, flags, training, momentum, eps, out)
+    return BatchNormFn.apply(x, gamma, beta, running_mean, running_var, residual, flags, training, momentum, eps, out, pre)
 
 
 class ReluInstNormFn(Function):
     """InstanceNorm3d(relu(x)), affine=False, eps 1e-5: statistics per (sample, channel)."""
 
     @staticmethod
-    def forward(ctx, x, eps, out):
+    def forward(ctx, x, eps, out, pre):
         x, rows, ldx = rows_view(x)
         B, C = x.shape[0], x.shape[-1]
         rpg = rows // B
         dev = x.device
         mean = torch.empty(B * C, dtype=torch.float32, device=dev)
         rstd = torch.empty(B * C, dtype=torch.float32, device=dev)
-        ws = _norm_ws(rpg, B, C, dev)
-        check(lib().corrif_norm_stats(P(x), ldx, rpg, B, C, NORM_RELU_IN, eps, P(mean), P(rstd), None, None, 0.0, P(ws), stream()),
-              "corrif_norm_stats")
+        if pre is not None and "part" in pre and pre["rpg"] == rpg and pre["G"] == B and pre["relu"]:
+            check(lib().corrif_norm_stats_finalize(P(pre["part"]), pre["chunks"], B, C, rpg, eps, P(mean), P(rstd), 0, 0, 0.0, stream()),
+                  "corrif_norm_stats_finalize")
+        else:
+            ws = _norm_ws(rpg, B, C, dev)
+            check(lib().corrif_norm_stats(P(x), ldx, rpg, B, C, NORM_RELU_IN, eps, P(mean), P(rstd), None, None, 0.0, P(ws), stream()),
+                  "corrif_norm_stats")
         if out is None:
             out = torch.empty(x.shape, dtype=torch.float32, device=dev)
         y, _, ldy = rows_view(out)
@@ -438,11 +460,11 @@ class ReluInstNormFn(Function):
         ws = _norm_ws(rpg, B, C, dev)
         check(lib().corrif_norm_bwd(P(gy), ldg, None, 0, P(x), ldx, P(mean), P(rstd), None, P(gx), C, None, 0, None, None,
                                     rpg, B, C, NORM_RELU_IN, 0, P(ws), stream()), "corrif_norm_bwd")
-        return gx, None, None
+        return gx, None, None, None
 
 
-def relu_instnorm(x, eps=1e-5, out=None):
-    return ReluInstNormFn.apply(x, eps, out)
+def relu_instnorm(x, eps=1e-5, out=None, pre=None):
+    return ReluInstNormFn.apply(x, eps, out, pre)
 
 
 # --------------------------------------------------------------------------------------- LayerNorm

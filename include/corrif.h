@@ -90,6 +90,12 @@ typedef struct CorrifGemm {
      * (n, rd*om_d + oo_d, rh*om_h + oo_h, rw*om_w + oo_w) of an OD x OH x OW grid (out_map = 0: row r itself).
      * Requires is_gemm = 0.  bias/addend are not combined with it. */
     int32_t out_map, OD, OH, OW, om_d, om_h, om_w, oo_d, oo_h, oo_w;
+    /* optional fused statistics for the BatchNorm / InstanceNorm that follows (mmvit4.py:41-45,173,206-208): the epilogue also
+     * accumulates, per output channel and per 64-row block, sum and sum of squares of the stored values (after max(.,0) when
+     * stats_relu) into stats_part[((g*N + c)*chunks + chunk)*2 + {0,1}] (doubles), g = row / stats_rows_per_group,
+     * chunks = ceil(stats_rows_per_group / 64); corrif_norm_stats_finalize turns them into mean / rstd.  Saves the
+     * separate statistics pass over the conv output.  stats_rows_per_group must be a multiple of 64 unless it equals M. */
+    double* stats_part; int64_t stats_rows_per_group; int32_t stats_relu;
 } CorrifGemm;
 int corrif_gemm_fwd(const CorrifGemm* p, void* stream);
 
@@ -186,6 +192,9 @@ size_t corrif_conv1x1_small_workspace(int64_t rows, int32_t Ci, int32_t Co);
 int corrif_norm_stats(const float* x, int64_t ldx, int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, float eps,
                       float* mean, float* rstd, float* running_mean, float* running_var, float momentum,
                       double* ws, void* stream);
+/* second half of corrif_norm_stats for partials produced by a GEMM epilogue (CorrifGemm.stats_part) */
+int corrif_norm_stats_finalize(const double* part, int32_t chunks, int32_t G, int32_t C, int64_t rows_per_group, float eps,
+                               float* mean, float* rstd, float* running_mean, float* running_var, float momentum, void* stream);
 /* rstd[c] = 1/sqrt(var[c] + eps) for eval mode */
 int corrif_norm_eval_rstd(const float* running_var, float eps, float* rstd, int32_t C, void* stream);
 /* y = act_out( gamma*(x' - mean)*rstd + beta + residual ) ; gamma/beta/residual may be NULL */

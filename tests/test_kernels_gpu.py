@@ -172,6 +172,42 @@ def test_batch_norm(ops, relu_in, relu_out, res, C, training):
     assert rel(rm_g, rm_r) < 1e-6 and rel(rv_g, rv_r) < 1e-6          # running statistics (momentum 0.1, unbiased var)
 
 
+@pytest.mark.parametrize("kind,Ci,Co,k,shape", [("bn", 64, 96, (1, 1, 1), (2, 3, 7, 9)), ("bn", 32, 256, (1, 3, 3), (2, 3, 14, 14)),
+                                                  ("in", 48, 48, (1, 1, 1), (3, 4, 8, 8)), ("in", 24, 24, (1, 1, 1), (2, 4, 56, 56))])
+def test_conv_with_norm_statistics_from_the_epilogue(ops, kind, Ci, Co, k, shape):
+    """conv -> BatchNorm (batch statistics) / conv -> ReLU -> InstanceNorm with the sum / sum-of-squares partials produced by the GEMM
+    epilogue (CorrifGemm.stats_part) instead of a separate pass over the conv output"""
+    B, D, Hh, W = shape
+    pad = (0, k[1] // 2, k[2] // 2)
+    x = rnd(B, Ci, D, Hh, W, seed=1)
+    w = rnd(Co, Ci, *k, seed=2, scale=1.0 / math.sqrt(Ci * k[1] * k[2]))
+    b = rnd(Co, seed=3) if kind == "in" else None
+    gamma, beta = 0.5 + torch.rand(Co, generator=torch.Generator().manual_seed(4)), rnd(Co, seed=5, scale=0.2)
+    rm, rv = torch.zeros(Co), torch.ones(Co)
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    cr = F.conv3d(xr, wr, b, 1, pad)
+    yr = F.batch_norm(cr, rm.clone(), rv.clone(), gamma, beta, True, 0.1, 1e-5) if kind == "bn" else F.instance_norm(F.relu(cr), eps=1e-5)
+    gy = rnd(*yr.shape, seed=6)
+    yr.backward(gy)
+    xg, wg = cl(x).to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    st = {"G": 1 if kind == "bn" else B, "relu": kind == "in"}
+    cg = ops.conv3d(xg, wg, b.to(DEV) if b is not None else None, (1, 1, 1), pad, False, None, stats=st)
+    assert "part" in st                                                   # the epilogue really produced the partials
+    if kind == "bn":
+        rm_g, rv_g = rm.to(DEV), rv.to(DEV)
+        yg = ops.batch_norm(cg, gamma.to(DEV), beta.to(DEV), rm_g, rv_g, None, False, False, True, 0.1, 1e-5, None, st)
+    else:
+        yg = ops.relu_instnorm(cg, 1e-5, None, st)
+    yg.backward(cl(gy).to(DEV))
+    torch.cuda.synchronize()
+    assert rel(ncdhw(yg), yr) < 3e-6
+    assert rel(ncdhw(xg.grad), xr.grad) < 2e-5 and rel(wg.grad, wr.grad) < 2e-5
+    if kind == "bn":
+        rm_r, rv_r = rm.clone(), rv.clone()
+        F.batch_norm(cr.detach(), rm_r, rv_r, gamma, beta, True, 0.1, 1e-5)
+        assert rel(rm_g, rm_r) < 1e-5 and rel(rv_g, rv_r) < 1e-5
+
+
 @pytest.mark.parametrize("C,shape", [(24, (2, 3, 10, 10)), (192, (3, 8, 8, 8)), (8, (2, 16, 16, 16))])
 def test_relu_instnorm(ops, C, shape):
     B, D, Hh, W = shape
