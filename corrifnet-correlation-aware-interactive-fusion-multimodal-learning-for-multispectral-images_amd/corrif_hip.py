@@ -112,6 +112,9 @@ _SIGS = {
     "corrif_bce_workspace": (C.c_size_t, [i64]),
     "corrif_jaccard": (i32, [ptr, ptr, i64, f32, ptr, ptr, ptr]),
     "corrif_jaccard_workspace": (C.c_size_t, [i64]),
+    "corrif_prep_means": (i32, [ptr, ptr, ptr, i32, i32, ptr, ptr, ptr]),
+    "corrif_prep_stack": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, ptr]),
+    "corrif_prep_workspace": (C.c_size_t, [i32, i32]),
     "corrif_adam_multi": (i32, [ptr, ptr, ptr, i32, f32, f32, f32, f32, f32, i32, ptr]),
     "corrif_adam_step": (i32, [ptr, ptr, ptr, ptr, i64, f32, f32, f32, f32, f32, i32, ptr]),
 }

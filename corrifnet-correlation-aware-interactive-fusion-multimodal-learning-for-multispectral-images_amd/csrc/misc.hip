@@ -1204,3 +1204,81 @@ extern "C" int corrif_adam_multi(const void* table, const int32_t* blk_tensor, c
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
+
+// ------------------------------------------------------------------ input pipeline (F8_IMAGES4.py:36-88), SURVEY 8(f) N3
+// raw patches are pixel-interleaved (HWC): rgb [N, HW, 3], all20 [N, HW, 20]; the network wants planar [N, 3 modalities, 3 bands, HW]
+// with the per-band TRAINING-SET mean removed: modality 0 = R,G,B; 1 = bands 9,10,11; 2 = bands 12,13,14 of the 20-band cube.
+__device__ __forceinline__ void prep_pixel(const float* __restrict__ rgb, const float* __restrict__ all20, int64_t px, float (&v)[9]) {
+    v[0] = rgb[px * 3]; v[1] = rgb[px * 3 + 1]; v[2] = rgb[px * 3 + 2];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[3 + c] = all20[px * 20 + 9 + c];
+}
+__global__ __launch_bounds__(256) void prep_means_partial_kernel(const float* __restrict__ rgb, const float* __restrict__ all20,
+                                                                 const int* __restrict__ trind, int ntr, int HW, double* __restrict__ part) {
+    __shared__ double red[4][9];
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int64_t total = (int64_t)ntr * HW;
+    GRID_STRIDE(i, total) {
+        const int s = (int)(i / HW);
+        const int64_t px = (int64_t)trind[s] * HW + (i - (int64_t)s * HW);
+        float v[9];
+        prep_pixel(rgb, all20, px, v);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) acc[c] += (double)v[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        double x = acc[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) part[(int64_t)blockIdx.x * 9 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void prep_means_final_kernel(const double* __restrict__ part, int nb, double inv_n, float* __restrict__ means) {
+    int c = threadIdx.x;
+    if (c >= 9) return;
+    double s = 0;
+    for (int k = 0; k < nb; ++k) s += part[(int64_t)k * 9 + c];
+    means[c] = (float)(s * inv_n);
+}
+__global__ void prep_stack_kernel(const float* __restrict__ rgb, const float* __restrict__ all20, const float* __restrict__ masks,
+                                  const float* __restrict__ means, float* __restrict__ images, float* __restrict__ targets, int N, int HW) {
+    const int64_t total = (int64_t)N * HW;
+    float mu[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) mu[c] = means[c];
+    GRID_STRIDE(i, total) {
+        const int64_t n = i / HW, p = i - n * HW;
+        float v[9];
+        prep_pixel(rgb, all20, i, v);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) images[(n * 9 + c) * HW + p] = v[c] - mu[c];       // [n][modality][band][pixel]
+        if (masks) {
+            const float m = masks[i];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) targets[(n * 3 + c) * HW + p] = m;              // mask repeated over 3 channels (:88)
+        }
+    }
+}
+extern "C" size_t corrif_prep_workspace(int32_t ntr, int32_t HW) { return (size_t)nblocks((int64_t)ntr * HW, 256, 1024) * 9 * sizeof(double); }
+extern "C" int corrif_prep_means(const float* rgb, const float* all20, const int32_t* trind, int32_t ntr, int32_t HW, float* means, double* ws,
+                                 void* stream) {
+    if (!rgb || !all20 || !trind || !means || !ws || ntr <= 0 || HW <= 0) return CORRIF_EINVAL;
+    const unsigned nb = nblocks((int64_t)ntr * HW, 256, 1024);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(prep_means_partial_kernel, dim3(nb), dim3(256), 0, s, rgb, all20, (const int*)trind, (int)ntr, (int)HW, ws);
+    CORRIF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(prep_means_final_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, (int)nb, 1.0 / ((double)ntr * HW), means);
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}
+extern "C" int corrif_prep_stack(const float* rgb, const float* all20, const float* masks, const float* means, float* images, float* targets,
+                                 int32_t N, int32_t HW, void* stream) {
+    if (!rgb || !all20 || !means || !images || N <= 0 || HW <= 0 || (masks && !targets)) return CORRIF_EINVAL;
+    hipLaunchKernelGGL(prep_stack_kernel, dim3(nblocks((int64_t)N * HW)), dim3(256), 0, (hipStream_t)stream, rgb, all20, masks, means, images,
+                       targets, (int)N, (int)HW);
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}

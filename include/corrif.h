@@ -305,6 +305,14 @@ size_t corrif_jaccard_workspace(int64_t n);
 int corrif_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int32_t step, void* stream);
 
+/* Input pipeline, F8_IMAGES4.py:36-88: raw pixel-interleaved patches rgb [N,HW,3] and all20 [N,HW,20] -> planar network
+ * input images [N,3,3,HW] = (R,G,B | bands 9,10,11 | bands 12,13,14) minus the per-band mean over the TRAINING samples `trind`
+ * (means[9], F8_IMAGES4.py:60-79), and targets [N,3,1,HW] = the mask repeated over three channels (F8_IMAGES4.py:88). */
+int corrif_prep_means(const float* rgb, const float* all20, const int32_t* trind, int32_t ntr, int32_t HW, float* means, double* ws, void* stream);
+int corrif_prep_stack(const float* rgb, const float* all20, const float* masks, const float* means, float* images, float* targets,
+                      int32_t N, int32_t HW, void* stream);
+size_t corrif_prep_workspace(int32_t ntr, int32_t HW);
+
 /* the same update for ALL parameters in one launch.  table: device array of {float* p; const float* g; float* m; float* v;
  * int64_t n;} (40 bytes each); block b updates elements [blk_off[b], blk_off[b]+1024) of tensor blk_tensor[b]. */
 int corrif_adam_multi(const void* table, const int32_t* blk_tensor, const int64_t* blk_off, int32_t nblocks, float lr, float beta1,

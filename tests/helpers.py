@@ -98,3 +98,13 @@ GRAD_KEYS = [
 # the 18 tensors that never receive a gradient
 NOGRAD_PREFIXES = ("RGB_decode_conv.", "NIR_decode_conv.", "SWIR_decode_conv.", "decoder_fuse.seg_d1.", "decoder_fuse.seg_d2.",
                    "decoder_fuse.seg_d3.", "decoder_fuse.seg_d4.", "decoder_fuse.seg_layer.", "fusion5.conv.")
+
+
+def make_raw_patches(N, seed=99, HW=224):
+    """synthetic stand-ins for the DSTL .mat patches the reference loader reads (F8_IMAGES4.py:20-34): reflectance-like floats"""
+    import numpy as np
+    r = np.random.RandomState(seed)
+    rgb = (r.rand(N, HW, HW, 3) * 255.0).astype(np.float32)
+    all20 = (r.rand(N, HW, HW, 20) * 1000.0 + np.arange(20, dtype=np.float32) * 37.0).astype(np.float32)
+    masks = (r.rand(N, HW, HW) > 0.7).astype(np.float32)
+    return rgb, all20, masks
