@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcorrif_gfx950.so")
+LIB_PATH = os.environ.get("CORRIF_LIB") or os.path.join(_HERE, "libcorrif_gfx950.so")      # CORRIF_LIB: A/B builds side by side
 _lib = None
 
 i32, i64, u64, f32 = C.c_int32, C.c_int64, C.c_uint64, C.c_float

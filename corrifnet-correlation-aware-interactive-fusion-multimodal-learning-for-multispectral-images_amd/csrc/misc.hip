@@ -11,6 +11,27 @@ static inline unsigned nblocks(int64_t n, int per = 256, int64_t cap = 16384) {
     if (b < 1) b = 1;
     return (unsigned)b;
 }
+// flat index -> (b, d, h, w, c4) with 32-bit multiply-shift divisions (the index-heavy resampling kernels were VALU-bound on
+// 64-bit '/' and '%': nearest 128^3 ran at 1.6 TB/s)
+struct Dec5 { FastDiv c, w, h, d; };
+static inline Dec5 make_dec5(int D, int H, int W, int C4) {
+    Dec5 q;
+    q.c = make_fastdiv((uint32_t)C4); q.w = make_fastdiv((uint32_t)W); q.h = make_fastdiv((uint32_t)H); q.d = make_fastdiv((uint32_t)D);
+    return q;
+}
+__device__ __forceinline__ void dec5(uint32_t i, const Dec5& q, int& b, int& d, int& h, int& w, int& c) {
+    uint32_t v = fdiv(i, q.c);
+    c = (int)(i - v * q.c.d);
+    uint32_t t = fdiv(v, q.w);
+    w = (int)(v - t * q.w.d);
+    v = t;
+    t = fdiv(v, q.h);
+    h = (int)(v - t * q.h.d);
+    v = t;
+    t = fdiv(v, q.d);
+    d = (int)(v - t * q.d.d);
+    b = (int)t;
+}
 #define GRID_STRIDE(i, n) for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 
 extern "C" int corrif_abi_version(void) { return CORRIF_ABI_VERSION; }
@@ -166,15 +187,12 @@ extern "C" int corrif_weight_repack(const float* in, float* out, int32_t O, int3
 
 // ------------------------------------------------------------------ max-pool (1,3,3)/(1,2,2) pad (0,1,1)
 __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int8_t* __restrict__ idx, int BD, int H, int W,
-                                   int Ho, int Wo, int C4) {
+                                   int Ho, int Wo, int C4, Dec5 q) {
     int64_t total = (int64_t)BD * Ho * Wo * C4;
     GRID_STRIDE(i, total) {
-        int c = (int)(i % C4);
-        int64_t v = i / C4;
-        int wo = (int)(v % Wo);
-        v /= Wo;
-        int ho = (int)(v % Ho);
-        int64_t bd = v / Ho;
+        int c, wo, ho, d0, b0;
+        dec5((uint32_t)i, q, b0, d0, ho, wo, c);        // q.d extent = BD, so b0 == 0 and d0 = bd
+        const int64_t bd = d0;
         f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         int bi[4] = {-1, -1, -1, -1};
 #pragma unroll
@@ -194,15 +212,12 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
     }
 }
 __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int8_t* __restrict__ idx, float* __restrict__ dx, int BD, int H,
-                                   int W, int Ho, int Wo, int C4) {
+                                   int W, int Ho, int Wo, int C4, Dec5 q) {
     int64_t total = (int64_t)BD * H * W * C4;
     GRID_STRIDE(i, total) {
-        int c = (int)(i % C4);
-        int64_t v = i / C4;
-        int w = (int)(v % W);
-        v /= W;
-        int h = (int)(v % H);
-        int64_t bd = v / H;
+        int c, w, h, d0, b0;
+        dec5((uint32_t)i, q, b0, d0, h, w, c);
+        const int64_t bd = d0;
         f32x4 acc = {0, 0, 0, 0};
         // outputs whose window covers (h, w): 2*ho-1+kh == h  -> ho in {(h+1)/2 (kh = h+1-2ho)}, kh in 0..2
         for (int kh = 0; kh < 3; ++kh) {
@@ -234,8 +249,9 @@ extern "C" int corrif_maxpool133_fwd(const float* x, float* y, int8_t* idx, int3
     if ((C & 3) || !al16(x) || !al16(y) || ((uintptr_t)idx & 3)) return CORRIF_EUNSUPPORTED;
     int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     int64_t total = (int64_t)B * D * Ho * Wo * (C / 4);
+    if (total >= ((int64_t)1 << 31)) return CORRIF_EUNSUPPORTED;
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, idx, B * D, (int)H, (int)W, Ho, Wo,
-                       C / 4);
+                       C / 4, make_dec5(B * D, Ho, Wo, C / 4));
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
@@ -245,8 +261,9 @@ extern "C" int corrif_maxpool133_bwd(const float* dy, const int8_t* idx, float* 
     if ((C & 3) || !al16(dy) || !al16(dx) || ((uintptr_t)idx & 3)) return CORRIF_EUNSUPPORTED;
     int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     int64_t total = (int64_t)B * D * H * W * (C / 4);
+    if (total >= ((int64_t)1 << 31)) return CORRIF_EUNSUPPORTED;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, B * D, (int)H, (int)W, Ho, Wo,
-                       C / 4);
+                       C / 4, make_dec5(B * D, H, W, C / 4));
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
@@ -268,15 +285,12 @@ __device__ __forceinline__ void axis_taps(const Axis& a, int o, int& i0, int& i1
     l0 = 1.0f - l1;
 }
 __global__ void trilinear_fwd_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy, int B, int C4, Axis ad,
-                                     Axis ah, Axis aw) {
+                                     Axis ah, Axis aw, Dec5 q) {
     int64_t total = (int64_t)B * ad.out * ah.out * aw.out * C4;
     GRID_STRIDE(i, total) {
-        int c = (int)(i % C4);
-        int64_t v = i / C4;
-        int wo = (int)(v % aw.out); v /= aw.out;
-        int ho = (int)(v % ah.out); v /= ah.out;
-        int dd = (int)(v % ad.out);
-        int64_t b = v / ad.out;
+        int c, wo, ho, dd, bi;
+        dec5((uint32_t)i, q, bi, dd, ho, wo, c);
+        const int64_t b = bi;
         int d0, d1, h0, h1, w0, w1;
         float ld0, ld1, lh0, lh1, lw0, lw1;
         axis_taps(ad, dd, d0, d1, ld0, ld1);
@@ -311,15 +325,12 @@ __device__ __forceinline__ void axis_range(const Axis& a, int i, int& lo, int& h
     if (hi > a.out - 1) hi = a.out - 1;
 }
 __global__ void trilinear_bwd_kernel(const float* __restrict__ dy, int64_t lddy, float* __restrict__ dx, int64_t lddx, int B, int C4,
-                                     Axis ad, Axis ah, Axis aw) {
+                                     Axis ad, Axis ah, Axis aw, Dec5 q) {
     int64_t total = (int64_t)B * ad.in * ah.in * aw.in * C4;
     GRID_STRIDE(i, total) {
-        int c = (int)(i % C4);
-        int64_t v = i / C4;
-        int wi = (int)(v % aw.in); v /= aw.in;
-        int hi_ = (int)(v % ah.in); v /= ah.in;
-        int di = (int)(v % ad.in);
-        int64_t b = v / ad.in;
+        int c, wi, hi_, di, bi;
+        dec5((uint32_t)i, q, bi, di, hi_, wi, c);
+        const int64_t b = bi;
         int dlo, dhi, hlo, hhi, wlo, whi;
         axis_range(ad, di, dlo, dhi);
         axis_range(ah, hi_, hlo, hhi);
@@ -352,8 +363,9 @@ extern "C" int corrif_trilinear_fwd(const float* x, int64_t ldx, float* y, int64
                                     int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, void* stream) {
     if (!resample_ok(x, ldx, y, ldy, B, C, Di, Hi, Wi, Do, Ho, Wo)) return CORRIF_EINVAL;
     int64_t total = (int64_t)B * Do * Ho * Wo * (C / 4);
+    if (total >= ((int64_t)1 << 31)) return CORRIF_EUNSUPPORTED;
     hipLaunchKernelGGL(trilinear_fwd_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, (int)B, C / 4,
-                       make_axis(Di, Do), make_axis(Hi, Ho), make_axis(Wi, Wo));
+                       make_axis(Di, Do), make_axis(Hi, Ho), make_axis(Wi, Wo), make_dec5(Do, Ho, Wo, C / 4));
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
@@ -361,8 +373,9 @@ extern "C" int corrif_trilinear_bwd(const float* dy, int64_t lddy, float* dx, in
                                     int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, void* stream) {
     if (!resample_ok(dy, lddy, dx, lddx, B, C, Di, Hi, Wi, Do, Ho, Wo)) return CORRIF_EINVAL;
     int64_t total = (int64_t)B * Di * Hi * Wi * (C / 4);
+    if (total >= ((int64_t)1 << 31)) return CORRIF_EUNSUPPORTED;
     hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx, lddx, (int)B, C / 4,
-                       make_axis(Di, Do), make_axis(Hi, Ho), make_axis(Wi, Wo));
+                       make_axis(Di, Do), make_axis(Hi, Ho), make_axis(Wi, Wo), make_dec5(Di, Hi, Wi, C / 4));
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
@@ -375,15 +388,12 @@ __device__ __forceinline__ int nearest_src(const NAxis& a, int o) {
     return s < a.in - 1 ? s : a.in - 1;
 }
 __global__ void nearest_fwd_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy, int B, int C4, NAxis ad,
-                                   NAxis ah, NAxis aw) {
+                                   NAxis ah, NAxis aw, Dec5 q) {
     int64_t total = (int64_t)B * ad.out * ah.out * aw.out * C4;
     GRID_STRIDE(i, total) {
-        int c = (int)(i % C4);
-        int64_t v = i / C4;
-        int wo = (int)(v % aw.out); v /= aw.out;
-        int ho = (int)(v % ah.out); v /= ah.out;
-        int dd = (int)(v % ad.out);
-        int64_t b = v / ad.out;
+        int c, wo, ho, dd, bi;
+        dec5((uint32_t)i, q, bi, dd, ho, wo, c);
+        const int64_t b = bi;
         int64_t irow = ((b * ad.in + nearest_src(ad, dd)) * ah.in + nearest_src(ah, ho)) * aw.in + nearest_src(aw, wo);
         int64_t orow = ((b * ad.out + dd) * ah.out + ho) * aw.out + wo;
         *reinterpret_cast<f32x4*>(y + orow * ldy + c * 4) = *reinterpret_cast<const f32x4*>(x + irow * ldx + c * 4);
@@ -399,15 +409,12 @@ __device__ __forceinline__ void nearest_range(const NAxis& a, int i, int& lo, in
     while (hi >= lo && nearest_src(a, hi) != i) --hi;
 }
 __global__ void nearest_bwd_kernel(const float* __restrict__ dy, int64_t lddy, float* __restrict__ dx, int64_t lddx, int B, int C4, NAxis ad,
-                                   NAxis ah, NAxis aw) {
+                                   NAxis ah, NAxis aw, Dec5 q) {
     int64_t total = (int64_t)B * ad.in * ah.in * aw.in * C4;
     GRID_STRIDE(i, total) {
-        int c = (int)(i % C4);
-        int64_t v = i / C4;
-        int wi = (int)(v % aw.in); v /= aw.in;
-        int hi_ = (int)(v % ah.in); v /= ah.in;
-        int di = (int)(v % ad.in);
-        int64_t b = v / ad.in;
+        int c, wi, hi_, di, bi;
+        dec5((uint32_t)i, q, bi, di, hi_, wi, c);
+        const int64_t b = bi;
         int dlo, dhi, hlo, hhi, wlo, whi;
         nearest_range(ad, di, dlo, dhi);
         nearest_range(ah, hi_, hlo, hhi);
@@ -426,8 +433,9 @@ extern "C" int corrif_nearest_fwd(const float* x, int64_t ldx, float* y, int64_t
                                   int32_t Do, int32_t Ho, int32_t Wo, void* stream) {
     if (!resample_ok(x, ldx, y, ldy, B, C, Di, Hi, Wi, Do, Ho, Wo)) return CORRIF_EINVAL;
     int64_t total = (int64_t)B * Do * Ho * Wo * (C / 4);
+    if (total >= ((int64_t)1 << 31)) return CORRIF_EUNSUPPORTED;
     hipLaunchKernelGGL(nearest_fwd_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, (int)B, C / 4,
-                       make_naxis(Di, Do), make_naxis(Hi, Ho), make_naxis(Wi, Wo));
+                       make_naxis(Di, Do), make_naxis(Hi, Ho), make_naxis(Wi, Wo), make_dec5(Do, Ho, Wo, C / 4));
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
@@ -435,23 +443,22 @@ extern "C" int corrif_nearest_bwd(const float* dy, int64_t lddy, float* dx, int6
                                   int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, void* stream) {
     if (!resample_ok(dy, lddy, dx, lddx, B, C, Di, Hi, Wi, Do, Ho, Wo)) return CORRIF_EINVAL;
     int64_t total = (int64_t)B * Di * Hi * Wi * (C / 4);
+    if (total >= ((int64_t)1 << 31)) return CORRIF_EUNSUPPORTED;
     hipLaunchKernelGGL(nearest_bwd_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx, lddx, (int)B, C / 4,
-                       make_naxis(Di, Do), make_naxis(Hi, Ho), make_naxis(Wi, Wo));
+                       make_naxis(Di, Do), make_naxis(Hi, Ho), make_naxis(Wi, Wo), make_dec5(Di, Hi, Wi, C / 4));
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
 
 // ------------------------------------------------------------------ adjoint of replicate padding (pad 1 on every side)
-__global__ void pad_fold_kernel(const float* __restrict__ dxp, float* __restrict__ dx, int64_t lddx, int B, int D, int H, int W, int C4) {
+__global__ void pad_fold_kernel(const float* __restrict__ dxp, float* __restrict__ dx, int64_t lddx, int B, int D, int H, int W, int C4,
+                                Dec5 q) {
     int64_t total = (int64_t)B * D * H * W * C4;
     const int Dp = D + 2, Hp = H + 2, Wp = W + 2;
     GRID_STRIDE(i, total) {
-        int c = (int)(i % C4);
-        int64_t v = i / C4;
-        int w = (int)(v % W); v /= W;
-        int h = (int)(v % H); v /= H;
-        int d = (int)(v % D);
-        int64_t b = v / D;
+        int c, w, h, d, bi;
+        dec5((uint32_t)i, q, bi, d, h, w, c);
+        const int64_t b = bi;
         int d0 = d == 0 ? 0 : d + 1, d1 = d == D - 1 ? D + 1 : d + 1;
         int h0 = h == 0 ? 0 : h + 1, h1 = h == H - 1 ? H + 1 : h + 1;
         int w0 = w == 0 ? 0 : w + 1, w1 = w == W - 1 ? W + 1 : w + 1;
@@ -467,8 +474,9 @@ extern "C" int corrif_pad_fold(const float* dxp, float* dx, int64_t lddx, int32_
     if (!dxp || !dx || B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return CORRIF_EINVAL;
     if ((C & 3) || (lddx & 3) || !al16(dxp) || !al16(dx)) return CORRIF_EUNSUPPORTED;
     int64_t total = (int64_t)B * D * H * W * (C / 4);
+    if (total >= ((int64_t)1 << 31)) return CORRIF_EUNSUPPORTED;
     hipLaunchKernelGGL(pad_fold_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, dxp, dx, lddx, (int)B, (int)D, (int)H, (int)W,
-                       C / 4);
+                       C / 4, make_dec5(D, H, W, C / 4));
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
