@@ -148,9 +148,12 @@ def main():
 
     torch.manual_seed(0)
     model = mmvit4.MMVit4().to(dev).train()
+    if os.environ.get("CORRIF_DECODER_SPLIT") is not None:   # A/B switch
+        model.decoder_split = os.environ["CORRIF_DECODER_SPLIT"] == "1"
     if os.environ.get("CORRIF_SERIAL") == "1":          # profiling aid: one stream, clean per-kernel attribution
         model.concurrent_branches = False
         model.decoder_fuse.concurrent_skips = False
+        model.decoder_split = False
     broadcast_module_state(model)
     reducer = GradAllReducer(model)
     B = args.batch
@@ -186,6 +189,7 @@ def main():
         # region with the three modality branches serialised on one stream (with concurrent streams an event pair also
         # spans the other streams' kernels, so per-kernel durations are only meaningful one stream at a time)
         model.concurrent_branches = False
+        split_was, model.decoder_split = model.decoder_split, False
         kt_steps = min(2, args.steps)
         timer.on = True
         for _ in range(kt_steps):
@@ -193,6 +197,7 @@ def main():
         torch.cuda.synchronize()
         timer.on = False
         model.concurrent_branches = True
+        model.decoder_split = split_was
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

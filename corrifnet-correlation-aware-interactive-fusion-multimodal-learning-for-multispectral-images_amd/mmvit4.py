@@ -234,7 +234,7 @@ class Decoder_fuse(nn.Module):
         self.concurrent_skips = True
         self._side = None
 
-    def forward(self, x1, x2, x3, x4, x5):
+    def forward(self, x1, x2, x3, x4, x5, lane=0):
         B, dev = x5.shape[0], x5.device
         stages = ((self.RFM4, x4, 16, self.d4_c1, self.d4_c2, self.d4_out),
                   (self.RFM3, x3, 32, self.d3_c1, self.d3_c2, self.d3_out),
@@ -245,12 +245,14 @@ class Decoder_fuse(nn.Module):
         # skip branches (RFM -> nearest upsample into the concat slice) only depend on the early-fusion outputs: run them on a
         # side stream next to the main chain (RFM5 -> up2 -> d*_c1 ...), which needs each of them only at its concat
         parts_s = [None] * 4
-        side = self._side if getattr(self, "_side", None) is not None else None
+        if self._side is None:
+            self._side = {}
+        side = self._side.get(lane)
         use_side = self.concurrent_skips and x5.is_cuda
         if use_side:
             cur = torch.cuda.current_stream()
             if side is None:
-                side = self._side = torch.cuda.Stream(device=dev)
+                side = self._side[lane] = torch.cuda.Stream(device=dev)
             side.wait_stream(cur)
             for t in (x1, x2, x3, x4) + tuple(cats):      # allocated on the caller's stream, used (and saved) on the side stream
                 t.record_stream(side)
@@ -391,6 +393,11 @@ class MMVit4(nn.Module):
         # workgroups per CU each) fill the 256 CUs together.  Same kernels, same order per branch: results are unchanged.
         self.concurrent_branches = True
         self._streams = None
+        # The decoder has no cross-sample coupling (InstanceNorm is per sample, no BatchNorm): run it as two half-batch chains on
+        # two streams so that the HBM-bound stages of one half (norm statistics / apply, resampling) overlap the MFMA-bound stages
+        # of the other.  Forward values are unchanged; decoder weight gradients become the sum of two half-batch reductions.
+        self.decoder_split = True
+        self._dec_streams = None
 
     @staticmethod
     def _level_shapes(B, D, H, W):
@@ -454,7 +461,24 @@ class MMVit4(nn.Module):
         pos = ops.cat_tokens(self.RGB_pos, self.NIR_pos, self.SWIR_pos, self.fused6_pos)
         y = self.multimodal_transformer(ops.cat_tokens(*mm), pos)                          # [B, 2048, 512]
         x6 = self.multimodal_decode_conv(y.view(B, P3, P3, P3, 4 * T))                     # 4 tokens -> one voxel (mmvit4.py:526)
-        return self.decoder_fuse(fused[0], fused[1], fused[2], fused[3], x6)
+        if not (self.decoder_split and B >= 2):
+            return self.decoder_fuse(fused[0], fused[1], fused[2], fused[3], x6)
+        h = B // 2
+        cur = torch.cuda.current_stream()
+        if self._dec_streams is None:
+            self._dec_streams = [torch.cuda.Stream(device=x.device) for _ in range(2)]
+        ins = [ops.split_batch(t, h) for t in (fused[0], fused[1], fused[2], fused[3], x6)]
+        outs = []
+        for k, st in enumerate(self._dec_streams):
+            st.wait_stream(cur)
+            for t in ins:
+                t[k].record_stream(st)
+            with torch.cuda.stream(st):
+                outs.append(self.decoder_fuse(*[t[k] for t in ins], lane=k))
+        for st, o in zip(self._dec_streams, outs):
+            cur.wait_stream(st)
+            o.record_stream(cur)
+        return ops.cat_batch(*outs)
 
 
 def Jaccard2(y, y_pred, epsilon=1e-8):

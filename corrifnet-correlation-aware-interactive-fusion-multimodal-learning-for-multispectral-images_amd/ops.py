@@ -787,6 +787,60 @@ def cat_channels(buf, *parts):
     return CatChannelsFn.apply([buf], *parts)
 
 
+class SplitBatchFn(Function):
+    """(t[:h], t[h:]) along the batch dimension (views); backward reassembles the two gradient halves with the copy kernel"""
+
+    @staticmethod
+    def forward(ctx, t, h):
+        ctx.h, ctx.shape = h, t.shape
+        return t[:h], t[h:]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        out = torch.empty(ctx.shape, dtype=torch.float32, device=(g0 if g0 is not None else g1).device)
+        per = out[0].numel()
+        for g, lo, n in ((g0, 0, ctx.h), (g1, ctx.h, ctx.shape[0] - ctx.h)):
+            dst = out[lo:lo + n]
+            if g is None:
+                dst.zero_()
+            else:
+                g = g.contiguous()
+                check(lib().corrif_copy2d(P(g), per, P(dst), per, n, per, 0, stream()), "corrif_copy2d")
+        return out, None
+
+
+def split_batch(t, h):
+    return SplitBatchFn.apply(t, h)
+
+
+class CatBatchFn(Function):
+    """torch.cat(parts, 0) for equally shaped sample blocks; backward hands out views of the gradient"""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        ns = [p.shape[0] for p in parts]
+        out = torch.empty((sum(ns),) + tuple(parts[0].shape[1:]), dtype=torch.float32, device=parts[0].device)
+        per = out[0].numel()
+        lo = 0
+        for p_, n in zip(parts, ns):
+            p_ = p_.contiguous()
+            check(lib().corrif_copy2d(P(p_), per, P(out[lo:lo + n]), per, n, per, 0, stream()), "corrif_copy2d")
+            lo += n
+        ctx.ns = ns
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, lo = [], 0
+        for n in ctx.ns:
+            outs.append(g[lo:lo + n])
+            lo += n
+        return tuple(outs)
+
+
+cat_batch = CatBatchFn.apply
+
+
 class CatTokensFn(Function):
     """torch.cat(dim=1) of [B, n_i, C] token blocks (mmvit4.py:515-521)."""
 
