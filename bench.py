@@ -149,11 +149,11 @@ def main():
     torch.manual_seed(0)
     model = mmvit4.MMVit4().to(dev).train()
     if os.environ.get("CORRIF_DECODER_SPLIT") is not None:   # A/B switch
-        model.decoder_split = os.environ["CORRIF_DECODER_SPLIT"] == "1"
+        model.decoder_split = int(os.environ["CORRIF_DECODER_SPLIT"])
     if os.environ.get("CORRIF_SERIAL") == "1":          # profiling aid: one stream, clean per-kernel attribution
         model.concurrent_branches = False
         model.decoder_fuse.concurrent_skips = False
-        model.decoder_split = False
+        model.decoder_split = 0
     broadcast_module_state(model)
     reducer = GradAllReducer(model)
     B = args.batch
@@ -189,7 +189,7 @@ def main():
         # region with the three modality branches serialised on one stream (with concurrent streams an event pair also
         # spans the other streams' kernels, so per-kernel durations are only meaningful one stream at a time)
         model.concurrent_branches = False
-        split_was, model.decoder_split = model.decoder_split, False
+        split_was, model.decoder_split = model.decoder_split, 0
         kt_steps = min(2, args.steps)
         timer.on = True
         for _ in range(kt_steps):

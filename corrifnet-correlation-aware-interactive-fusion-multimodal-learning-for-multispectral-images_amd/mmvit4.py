@@ -396,7 +396,7 @@ class MMVit4(nn.Module):
         # The decoder has no cross-sample coupling (InstanceNorm is per sample, no BatchNorm): run it as two half-batch chains on
         # two streams so that the HBM-bound stages of one half (norm statistics / apply, resampling) overlap the MFMA-bound stages
         # of the other.  Forward values are unchanged; decoder weight gradients become the sum of two half-batch reductions.
-        self.decoder_split = True
+        self.decoder_split = 2          # number of sample groups (0 / 1 = off)
         self._dec_streams = None
 
     @staticmethod
@@ -461,23 +461,25 @@ class MMVit4(nn.Module):
         pos = ops.cat_tokens(self.RGB_pos, self.NIR_pos, self.SWIR_pos, self.fused6_pos)
         y = self.multimodal_transformer(ops.cat_tokens(*mm), pos)                          # [B, 2048, 512]
         x6 = self.multimodal_decode_conv(y.view(B, P3, P3, P3, 4 * T))                     # 4 tokens -> one voxel (mmvit4.py:526)
-        if not (self.decoder_split and B >= 2):
+        lanes = min(int(self.decoder_split), B) if self.decoder_split else 1
+        if lanes < 2:
             return self.decoder_fuse(fused[0], fused[1], fused[2], fused[3], x6)
-        h = B // 2
         cur = torch.cuda.current_stream()
-        if self._dec_streams is None:
-            self._dec_streams = [torch.cuda.Stream(device=x.device) for _ in range(2)]
-        ins = [ops.split_batch(t, h) for t in (fused[0], fused[1], fused[2], fused[3], x6)]
+        if self._dec_streams is None or len(self._dec_streams) < lanes:
+            self._dec_streams = [torch.cuda.Stream(device=x.device) for _ in range(lanes)]
+        bounds = [B * k // lanes for k in range(lanes + 1)]
+        ins = [ops.split_batch(t, bounds) for t in (fused[0], fused[1], fused[2], fused[3], x6)]
         outs = []
-        for k, st in enumerate(self._dec_streams):
+        for k in range(lanes):
+            st = self._dec_streams[k]
             st.wait_stream(cur)
             for t in ins:
                 t[k].record_stream(st)
             with torch.cuda.stream(st):
                 outs.append(self.decoder_fuse(*[t[k] for t in ins], lane=k))
-        for st, o in zip(self._dec_streams, outs):
-            cur.wait_stream(st)
-            o.record_stream(cur)
+        for k in range(lanes):
+            cur.wait_stream(self._dec_streams[k])
+            outs[k].record_stream(cur)
         return ops.cat_batch(*outs)
 
 

@@ -788,18 +788,20 @@ def cat_channels(buf, *parts):
 
 
 class SplitBatchFn(Function):
-    """(t[:h], t[h:]) along the batch dimension (views); backward reassembles the two gradient halves with the copy kernel"""
+    """t[b0:b1], t[b1:b2], ... along the batch dimension (views); backward reassembles the gradient pieces with the copy kernel"""
 
     @staticmethod
-    def forward(ctx, t, h):
-        ctx.h, ctx.shape = h, t.shape
-        return t[:h], t[h:]
+    def forward(ctx, t, bounds):
+        ctx.bounds, ctx.shape = list(bounds), t.shape
+        return tuple(t[bounds[k]:bounds[k + 1]] for k in range(len(bounds) - 1))
 
     @staticmethod
-    def backward(ctx, g0, g1):
-        out = torch.empty(ctx.shape, dtype=torch.float32, device=(g0 if g0 is not None else g1).device)
+    def backward(ctx, *gs):
+        dev = next(g for g in gs if g is not None).device
+        out = torch.empty(ctx.shape, dtype=torch.float32, device=dev)
         per = out[0].numel()
-        for g, lo, n in ((g0, 0, ctx.h), (g1, ctx.h, ctx.shape[0] - ctx.h)):
+        for k, g in enumerate(gs):
+            lo, n = ctx.bounds[k], ctx.bounds[k + 1] - ctx.bounds[k]
             dst = out[lo:lo + n]
             if g is None:
                 dst.zero_()
@@ -809,8 +811,8 @@ class SplitBatchFn(Function):
         return out, None
 
 
-def split_batch(t, h):
-    return SplitBatchFn.apply(t, h)
+def split_batch(t, bounds):
+    return SplitBatchFn.apply(t, bounds)
 
 
 class CatBatchFn(Function):
