@@ -113,40 +113,34 @@ __global__ __launch_bounds__(256) void conv3_patch_kernel(PatchArgs p) {
             }
         }
         // ---- stage the halo'd input patch of this channel chunk; loads are issued in batches of 8 per thread so that
-        //      their latencies overlap (a load -> wait -> ds_write loop is bound by 14 serial HBM round trips)
+        //      their latencies overlap (a load -> wait -> ds_write loop is bound by 14 serial HBM round trips).  The loads are
+        //      unconditional from the clamped voxel (always mapped) and zero padding is applied at the LDS store: a load under a
+        //      branch makes the compiler drain vmcnt at the join.
         {
             constexpr int C4 = CC / 4, UB = 8;
             const int total = NPV * C4;
             for (int i0 = tid; i0 < total; i0 += 256 * UB) {
                 f32x4 v[UB];
                 int dst[UB];
+                bool zf[UB];
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
                     const int i = i0 + u * 256;
-                    v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    dst[u] = -1;
-                    if (i < total) {
-                        const int pv = i / C4, c4 = i - pv * C4;
-                        const uint32_t pd = fdiv((uint32_t)pv, p.dHW);
-                        const uint32_t rem = pv - pd * p.dHW.d;
-                        const uint32_t ph = fdiv(rem, p.dW);
-                        const uint32_t pw = rem - ph * p.dW.d;
-                        int sd = od0 + (int)pd - p.pad, sh = oh0 + (int)ph - p.pad, sw = ow0 + (int)pw - p.pad;
-                        bool ok = true;
-                        if (p.clamp) {
-                            sd = min(max(sd, 0), p.Sd - 1);
-                            sh = min(max(sh, 0), p.Sh - 1);
-                            sw = min(max(sw, 0), p.Sw - 1);
-                        } else {
-                            ok = sd >= 0 && sd < p.Sd && sh >= 0 && sh < p.Sh && sw >= 0 && sw < p.Sw;
-                        }
-                        dst[u] = pv * Cfg::CP + c4 * 4;
-                        if (ok) v[u] = *reinterpret_cast<const f32x4*>(Xb + ((int64_t)(sd * p.Sh + sh) * p.Sw + sw) * p.ldx + ch * CC + c4 * 4);
-                    }
+                    const int ic = min(i, total - 1);
+                    const int pv = ic / C4, c4 = ic - pv * C4;
+                    const uint32_t pd = fdiv((uint32_t)pv, p.dHW);
+                    const uint32_t rem = pv - pd * p.dHW.d;
+                    const uint32_t ph = fdiv(rem, p.dW);
+                    const uint32_t pw = rem - ph * p.dW.d;
+                    const int sd = od0 + (int)pd - p.pad, sh = oh0 + (int)ph - p.pad, sw = ow0 + (int)pw - p.pad;
+                    const int cd = min(max(sd, 0), p.Sd - 1), chh = min(max(sh, 0), p.Sh - 1), cw = min(max(sw, 0), p.Sw - 1);
+                    zf[u] = !p.clamp && (cd != sd || chh != sh || cw != sw);
+                    dst[u] = i < total ? pv * Cfg::CP + c4 * 4 : -1;
+                    v[u] = *reinterpret_cast<const f32x4*>(Xb + ((int64_t)(cd * p.Sh + chh) * p.Sw + cw) * p.ldx + ch * CC + c4 * 4);
                 }
 #pragma unroll
                 for (int u = 0; u < UB; ++u)
-                    if (dst[u] >= 0) *reinterpret_cast<f32x4*>(patch + dst[u]) = v[u];
+                    if (dst[u] >= 0) *reinterpret_cast<f32x4*>(patch + dst[u]) = zf[u] ? (f32x4){0.f, 0.f, 0.f, 0.f} : v[u];
             }
         }
         __syncthreads();
@@ -311,10 +305,9 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_wgrad_kernel(PatchWgArgs p
                 const int v = i / NG, g = i - v * NG;
                 const int vw = v & 15, vh = (v >> 4) & (TH - 1), vd = v >> (4 + p.lth);
                 const int od = od0 + vd, oh = oh0 + vh, ow = ow0 + vw;
-                f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                if (od < p.Od && oh < p.Oh && ow < p.Ow && g * 4 < p.Co)
-                    val = *reinterpret_cast<const f32x4*>(gb + ((int64_t)(od * p.Oh + oh) * p.Ow + ow) * p.lddy + g * 4);
-                *reinterpret_cast<f32x4*>(dys + v * DP + g * 4) = val;
+                const bool ok = od < p.Od && oh < p.Oh && ow < p.Ow && g * 4 < p.Co;
+                const f32x4 val = *reinterpret_cast<const f32x4*>(gb + (ok ? ((int64_t)(od * p.Oh + oh) * p.Ow + ow) * p.lddy + g * 4 : 0));
+                *reinterpret_cast<f32x4*>(dys + v * DP + g * 4) = ok ? val : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
         const float* __restrict__ xb = p.X + (int64_t)b * p.Sd * p.Sh * p.Sw * p.ldx;
@@ -327,33 +320,25 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_wgrad_kernel(PatchWgArgs p
                 for (int i0 = tid; i0 < total; i0 += 256 * UB) {
                     f32x4 v[UB];
                     int dst[UB];
+                    bool zf[UB];
 #pragma unroll
                     for (int u = 0; u < UB; ++u) {
                         const int i = i0 + u * 256;
-                        v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        dst[u] = -1;
-                        if (i < total) {
-                            const int pv = i / C4, c4 = i - pv * C4;
-                            const uint32_t pd = fdiv((uint32_t)pv, p.dHW);
-                            const uint32_t rem = pv - pd * p.dHW.d;
-                            const uint32_t ph = fdiv(rem, p.dW);
-                            const uint32_t pw = rem - ph * p.dW.d;
-                            int sd = od0 + (int)pd - p.pad, sh = oh0 + (int)ph - p.pad, sw = ow0 + (int)pw - p.pad;
-                            bool ok = true;
-                            if (p.clamp) {
-                                sd = min(max(sd, 0), p.Sd - 1);
-                                sh = min(max(sh, 0), p.Sh - 1);
-                                sw = min(max(sw, 0), p.Sw - 1);
-                            } else {
-                                ok = sd >= 0 && sd < p.Sd && sh >= 0 && sh < p.Sh && sw >= 0 && sw < p.Sw;
-                            }
-                            dst[u] = pv * CP + c4 * 4;
-                            if (ok) v[u] = *reinterpret_cast<const f32x4*>(xb + ((int64_t)(sd * p.Sh + sh) * p.Sw + sw) * p.ldx + c_lo + ch * CC + c4 * 4);
-                        }
+                        const int ic = min(i, total - 1);          // unconditional clamped loads, zero fill at the LDS store (see the forward kernel)
+                        const int pv = ic / C4, c4 = ic - pv * C4;
+                        const uint32_t pd = fdiv((uint32_t)pv, p.dHW);
+                        const uint32_t rem = pv - pd * p.dHW.d;
+                        const uint32_t ph = fdiv(rem, p.dW);
+                        const uint32_t pw = rem - ph * p.dW.d;
+                        const int sd = od0 + (int)pd - p.pad, sh = oh0 + (int)ph - p.pad, sw = ow0 + (int)pw - p.pad;
+                        const int cd = min(max(sd, 0), p.Sd - 1), chh = min(max(sh, 0), p.Sh - 1), cw = min(max(sw, 0), p.Sw - 1);
+                        zf[u] = !p.clamp && (cd != sd || chh != sh || cw != sw);
+                        dst[u] = i < total ? pv * CP + c4 * 4 : -1;
+                        v[u] = *reinterpret_cast<const f32x4*>(xb + ((int64_t)(cd * p.Sh + chh) * p.Sw + cw) * p.ldx + c_lo + ch * CC + c4 * 4);
                     }
 #pragma unroll
                     for (int u = 0; u < UB; ++u)
-                        if (dst[u] >= 0) *reinterpret_cast<f32x4*>(patch + dst[u]) = v[u];
+                        if (dst[u] >= 0) *reinterpret_cast<f32x4*>(patch + dst[u]) = zf[u] ? (f32x4){0.f, 0.f, 0.f, 0.f} : v[u];
                 }
             }
             __syncthreads();

@@ -13,7 +13,9 @@
 #include "igemm_args.h"
 
 
-template <int BM, int BN, int WM, int WN, int VEC>
+// GEMM / BL (= is_gemm / b_layout) are compile-time: one straight-line K loop per variant lets the compiler keep all tile
+// loads in flight together (run-time variants shared basic blocks and forced vmcnt drains at the joins).
+template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL>
 __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AI = BM / 32, BI = BN / 32;      // float4 chunks per thread per K tile
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
     for (int i = 0; i < AI; ++i) {
         int row = m0 + ar + 32 * i;
         if (row < p.M) {
-            if (p.g.is_gemm) {
+            if constexpr (GEMM) {
                 a_base[i] = (int64_t)row * p.lda;
                 a_pack[i] = 0;
             } else {
@@ -67,6 +69,11 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
 
     f32x4 ra[AI], rb[BI];
     const int nk = (p.K + BK - 1) / BK;
+    int a_off[AI];                        // cached per-row source offsets (floats inside the sample) of tap cur_tap; -1 = zero padding
+    uint32_t okA = 0, okB = 0;            // validity bits of ra[] / rb[] (applied at the LDS store)
+    int cur_tap = -1, nx_tap = 0, nx_c4 = kc;   // (tap, float4 chunk) of this thread's chunk in the NEXT tile to load (tiles load in order)
+#pragma unroll
+    for (int i = 0; i < AI; ++i) a_off[i] = -1;
 
     auto load_tile = [&](int kt) {
         // ---------------- A (gathered) ----------------
@@ -74,29 +81,36 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
         const int k = q * 4;
         bool kin = k < p.K;
         if constexpr (VEC == 4) {
-            int tap = 0, c = k, td = 0, th = 0, tw = 0;
-            if (!p.g.is_gemm && kin) {
-                tap = q / p.Cs4;
-                c = (q - tap * p.Cs4) * 4;
-                if (p.ntap_sel) tap = p.tap_sel[tap];
-                td = (int)fdiv((uint32_t)tap, p.g.dKhw);
-                int rem = tap - td * (int)p.g.dKhw.d;
-                th = (int)fdiv((uint32_t)rem, p.g.dKw);
-                tw = rem - th * (int)p.g.dKw.d;
-            }
+            int c = k;
+            if (!GEMM && kin) {
+                // K runs (tap, channel): the voxel offsets of this thread's rows only change when its chunk crosses into a new
+                // tap, so they are cached and re-derived on tap change (every Cs/32 K tiles), not per tile.
+                while (nx_c4 >= p.Cs4) { nx_c4 -= p.Cs4; ++nx_tap; }
+                c = nx_c4 * 4;
+                if (nx_tap != cur_tap) {
+                    cur_tap = nx_tap;
+                    const int tap = p.ntap_sel ? p.tap_sel[nx_tap] : nx_tap;
+                    const int td = (int)fdiv((uint32_t)tap, p.g.dKhw);
+                    const int rem = tap - td * (int)p.g.dKhw.d;
+                    const int th = (int)fdiv((uint32_t)rem, p.g.dKw);
+                    const int tw = rem - th * (int)p.g.dKw.d;
 #pragma unroll
-            for (int i = 0; i < AI; ++i) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (kin && a_pack[i] != 0xFFFFFFFFu) {
-                    if (p.g.is_gemm) {
-                        v = *reinterpret_cast<const f32x4*>(A + a_base[i] + k);
-                    } else {
+                    for (int i = 0; i < AI; ++i) {
                         int vox;
-                        if (gather_voxel(a_pack[i], td, th, tw, p.g, vox))
-                            v = *reinterpret_cast<const f32x4*>(A + a_base[i] + (int64_t)vox * p.lda + c);
+                        a_off[i] = (a_pack[i] != 0xFFFFFFFFu && gather_voxel(a_pack[i], td, th, tw, p.g, vox)) ? vox * (int)p.lda : -1;
                     }
                 }
-                ra[i] = v;
+                nx_c4 += 8;
+            }
+            // Loads are UNCONDITIONAL (masked-off lanes read the 16 bytes at A, always mapped) and the zero fill happens at the
+            // LDS store: a load under a branch makes the compiler drain vmcnt at every join, serialising the round trips.
+            okA = 0;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                const bool ok = kin && (GEMM ? a_pack[i] != 0xFFFFFFFFu : a_off[i] >= 0);
+                const int64_t off = GEMM ? a_base[i] + k : a_base[i] + a_off[i] + c;
+                ra[i] = *reinterpret_cast<const f32x4*>(A + (ok ? off : 0));
+                okA |= (uint32_t)ok << i;
             }
         } else {   // Cs == 1 (the stem): the 4 k's of a chunk are 4 different taps, scalar gathers
             int td[4], th[4], tw[4];
@@ -110,28 +124,29 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
                 th[e] = (int)fdiv((uint32_t)rem, p.g.dKw);
                 tw[e] = rem - th[e] * (int)p.g.dKw.d;
             }
+            okA = ~0u;                     // this path zero-fills per element below
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (kin && a_pack[i] != 0xFFFFFFFFu) {
+                f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        int vox;
-                        if (tok[e] && gather_voxel(a_pack[i], td[e], th[e], tw[e], p.g, vox))
-                            v[e] = A[a_base[i] + (int64_t)vox * p.lda];
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    int vox;
+                    const bool ok = kin && a_pack[i] != 0xFFFFFFFFu && tok[e] && gather_voxel(a_pack[i], td[e], th[e], tw[e], p.g, vox);
+                    const float x = A[ok ? a_base[i] + (int64_t)vox * p.lda : 0];      // unconditional load, select afterwards
+                    v[e] = ok ? x : 0.f;
                 }
                 ra[i] = v;
             }
         }
         // ---------------- B ----------------
-        if (p.b_layout == 0) {              // [N][K]
+        okB = 0;
+        if constexpr (BL == 0) {              // [N][K]
 #pragma unroll
             for (int i = 0; i < BI; ++i) {
-                int n = n0 + ar + 32 * i;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (kin && n < p.N) v = *reinterpret_cast<const f32x4*>(B + (int64_t)n * p.ldb + k);
-                rb[i] = v;
+                const int n = n0 + ar + 32 * i;
+                const bool ok = kin && n < p.N;
+                rb[i] = *reinterpret_cast<const f32x4*>(B + (ok ? (int64_t)n * p.ldb + k : 0));
+                okB |= (uint32_t)ok << i;
             }
         } else {                            // [K][N]: float4 along n
             constexpr int CN = BN / 4;
@@ -140,26 +155,28 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
                 int cidx = tid + 256 * i;
                 int nc = cidx % CN, kk = cidx / CN;
                 int kg = kt * BK + kk, n = n0 + nc * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (kg < p.K && n < p.N) v = *reinterpret_cast<const f32x4*>(B + (int64_t)kg * p.ldb + n);
-                rb[i] = v;
+                const bool ok = kg < p.K && n < p.N;
+                rb[i] = *reinterpret_cast<const f32x4*>(B + (ok ? (int64_t)kg * p.ldb + n : 0));
+                okB |= (uint32_t)ok << i;
             }
         }
     };
     auto store_tile = [&]() {
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(ar + 32 * i) * LDS_PITCH + kc * 4]) = ra[i];
-        if (p.b_layout == 0) {
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(ar + 32 * i) * LDS_PITCH + kc * 4]) = (okA >> i) & 1 ? ra[i] : zero4;
+        if constexpr (BL == 0) {
 #pragma unroll
-            for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(ar + 32 * i) * LDS_PITCH + kc * 4]) = rb[i];
+            for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(ar + 32 * i) * LDS_PITCH + kc * 4]) = (okB >> i) & 1 ? rb[i] : zero4;
         } else {
             constexpr int CN = BN / 4;
 #pragma unroll
             for (int i = 0; i < BI; ++i) {
                 int cidx = tid + 256 * i;
                 int nc = cidx % CN, kk = cidx / CN;
+                const f32x4 v = (okB >> i) & 1 ? rb[i] : zero4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Bs[(nc * 4 + e) * LDS_PITCH + kk] = rb[i][e];
+                for (int e = 0; e < 4; ++e) Bs[(nc * 4 + e) * LDS_PITCH + kk] = v[e];
             }
         }
     };
@@ -287,7 +304,15 @@ template <int BM, int BN, int WM, int WN, int VEC = 4>
 static int launch_fwd(const GemmArgs& a, int Z, hipStream_t s) {
     uint32_t tiles = (uint32_t)((a.M + BM - 1) / BM) * (uint32_t)((a.N + BN - 1) / BN);
     dim3 grid(tiles, 1, Z);
-    hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC>), grid, dim3(256), 0, s, a);
+    if constexpr (VEC == 1) {
+        hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, 1, false, 0>), grid, dim3(256), 0, s, a);
+    } else if (a.g.is_gemm) {
+        if (a.b_layout == 0) hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC, true, 0>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC, true, 1>), grid, dim3(256), 0, s, a);
+    } else {
+        if (a.b_layout == 0) hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC, false, 0>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC, false, 1>), grid, dim3(256), 0, s, a);
+    }
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
@@ -306,6 +331,7 @@ extern "C" int corrif_gemm_fwd(const CorrifGemm* p, void* stream) {
     if (p->b_layout == 1 && (p->N & 3)) return CORRIF_EUNSUPPORTED;
     if (p->b_layout != 0 && p->b_layout != 1) return CORRIF_EINVAL;
     if (!geom_ok(p->g)) return CORRIF_EINVAL;
+    if (!p->g.is_gemm && (int64_t)p->g.Sd * p->g.Sh * p->g.Sw * p->lda >= (int64_t)1 << 31) return CORRIF_EUNSUPPORTED;   // 32-bit in-sample offsets
     if (p->ntap_sel < 0 || p->ntap_sel > 28 || (p->ntap_sel && (p->g.is_gemm || scalar))) return CORRIF_EINVAL;
     if (p->out_map && (p->g.is_gemm || p->addend || p->N > 4096 * 1024)) return CORRIF_EINVAL;
     if (!p->g.is_gemm && !scalar && p->K != (p->ntap_sel ? p->ntap_sel : p->g.kd * p->g.kh * p->g.kw) * p->Cs) return CORRIF_EINVAL;
@@ -357,7 +383,7 @@ extern "C" int corrif_gemm_fwd(const CorrifGemm* p, void* stream) {
 // W-type: contraction over rows.  LDS tiles are [32 rows][BM] and [32 rows][BN]; MFMA lane (i, h)
 // reads element [2s+h][i] of each (ds_read_b32, lanes consecutive -> conflict free).
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int VEC>
+template <int BM, int BN, int WM, int WN, int VEC, bool GEMM>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int PA = BM + 4, PB = BN + 4;
@@ -387,7 +413,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     bool tok[VEC == 1 ? 4 : 1];
     td[0] = th[0] = tw[0] = 0;
     tok[0] = true;
-    if (!p.g.is_gemm && jin) {
+    if (!GEMM && jin) {
 #pragma unroll
         for (int e = 0; e < (VEC == 1 ? 4 : 1); ++e) {
             int tap = (VEC == 1) ? j + e : j / p.Cs;
@@ -412,44 +438,51 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
     f32x4 ra[AI], rb[BI];
+    uint32_t okA = 0, okB = 0;            // validity bits of ra[] / rb[]; loads are unconditional, zero fill happens at the LDS store
     auto load_tile = [&](int r0) {
+        okA = okB = 0;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            int row = r0 + arow + (256 / CA) * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ain && row < r_end) v = *reinterpret_cast<const f32x4*>(A + (int64_t)row * p.lda + am);
-            ra[i] = v;
+            const int row = r0 + arow + (256 / CA) * i;
+            const bool ok = ain && row < r_end;
+            ra[i] = *reinterpret_cast<const f32x4*>(A + (ok ? (int64_t)row * p.lda + am : 0));
+            okA |= (uint32_t)ok << i;
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
-            int row = r0 + br + (256 / CB) * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (jin && row < r_end) {
-                if (p.g.is_gemm) {
-                    v = *reinterpret_cast<const f32x4*>(B + (int64_t)row * p.ldb + j);
+            const int row = r0 + br + (256 / CB) * i;
+            const bool rin = jin && row < r_end;
+            if constexpr (GEMM) {
+                rb[i] = *reinterpret_cast<const f32x4*>(B + (rin ? (int64_t)row * p.ldb + j : 0));
+                okB |= (uint32_t)rin << i;
+            } else {
+                uint32_t n, pk;
+                int vox;
+                decode_row((uint32_t)(rin ? row : 0), p.g, n, pk);
+                if constexpr (VEC == 4) {
+                    const bool ok = gather_voxel(pk, td[0], th[0], tw[0], p.g, vox) && rin;
+                    rb[i] = *reinterpret_cast<const f32x4*>(B + (ok ? (int64_t)n * p.g.sample_pitch + (int64_t)vox * p.ldb + cch : 0));
+                    okB |= (uint32_t)ok << i;
                 } else {
-                    uint32_t n, pk;
-                    int vox;
-                    decode_row((uint32_t)row, p.g, n, pk);
-                    if constexpr (VEC == 4) {
-                        if (gather_voxel(pk, td[0], th[0], tw[0], p.g, vox))
-                            v = *reinterpret_cast<const f32x4*>(B + (int64_t)n * p.g.sample_pitch + (int64_t)vox * p.ldb + cch);
-                    } else {
+                    f32x4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (tok[e] && gather_voxel(pk, td[e], th[e], tw[e], p.g, vox))
-                                v[e] = B[(int64_t)n * p.g.sample_pitch + (int64_t)vox * p.ldb];
+                    for (int e = 0; e < 4; ++e) {
+                        const bool ok = gather_voxel(pk, td[e], th[e], tw[e], p.g, vox) && rin && tok[e];
+                        const float x = B[ok ? (int64_t)n * p.g.sample_pitch + (int64_t)vox * p.ldb : 0];
+                        v[e] = ok ? x : 0.f;
                     }
+                    rb[i] = v;
+                    okB |= 1u << i;
                 }
             }
-            rb[i] = v;
         }
     };
     auto store_tile = [&]() {
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(arow + (256 / CA) * i) * PA + ac * 4]) = ra[i];
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(arow + (256 / CA) * i) * PA + ac * 4]) = (okA >> i) & 1 ? ra[i] : zero4;
 #pragma unroll
-        for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(br + (256 / CB) * i) * PB + jc * 4]) = rb[i];
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(br + (256 / CB) * i) * PB + jc * 4]) = (okB >> i) & 1 ? rb[i] : zero4;
     };
 
     const int fi = lane & 31, fh = lane >> 5;
@@ -577,12 +610,17 @@ extern "C" int corrif_wgrad(const CorrifWgrad* p, void* stream) {
     dim3 grid(tiles, 1, p->splits > 1 ? p->splits : p->Z);
     if (scalar) {
         grid.x = (uint32_t)((p->M + 63) / 64) * (uint32_t)((p->N + 127) / 128);
-        hipLaunchKernelGGL((wgrad_kernel<64, 128, 2, 2, 1>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((wgrad_kernel<64, 128, 2, 2, 1, false>), grid, dim3(256), 0, s, a);
     } else if (BN == 256) {
         int rc = launch_smallm_wgrad(a, (int)grid.z, s);
         if (rc != CORRIF_OK) return rc;
-    } else if (BM == 32) hipLaunchKernelGGL((wgrad_kernel<32, 128, 1, 4, 4>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_kernel<64, 128, 2, 2, 4>), grid, dim3(256), 0, s, a);
+    } else if (BM == 32) {
+        if (a.g.is_gemm) hipLaunchKernelGGL((wgrad_kernel<32, 128, 1, 4, 4, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wgrad_kernel<32, 128, 1, 4, 4, false>), grid, dim3(256), 0, s, a);
+    } else {
+        if (a.g.is_gemm) hipLaunchKernelGGL((wgrad_kernel<64, 128, 2, 2, 4, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wgrad_kernel<64, 128, 2, 2, 4, false>), grid, dim3(256), 0, s, a);
+    }
     CORRIF_CHECK_LAUNCH();
     if (p->splits > 1) {
         int64_t n = (int64_t)p->M * p->N;

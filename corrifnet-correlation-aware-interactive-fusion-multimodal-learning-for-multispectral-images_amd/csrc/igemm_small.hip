@@ -65,29 +65,33 @@ __global__ __launch_bounds__(256) void smalln_fwd_kernel(GemmArgs p) {
             th = (int)fdiv((uint32_t)rem, p.g.dKw);
             tw = rem - th * (int)p.g.dKw.d;
         }
+        // unconditional loads (masked lanes read the always-mapped first 16 bytes), zero fill by select: see igemm.hip
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (kin && a_pack[i] != 0xFFFFFFFFu) {
-                if (p.g.is_gemm) {
-                    v = *reinterpret_cast<const f32x4*>(A + a_base[i] + k);
-                } else {
-                    int vox;
-                    if (gather_voxel(a_pack[i], td, th, tw, p.g, vox))
-                        v = *reinterpret_cast<const f32x4*>(A + a_base[i] + (int64_t)vox * p.lda + c);
-                }
+            bool ok = kin && a_pack[i] != 0xFFFFFFFFu;
+            int64_t off = a_base[i] + k;
+            if (!p.g.is_gemm) {
+                int vox;
+                ok = gather_voxel(a_pack[i], td, th, tw, p.g, vox) && ok;
+                off = a_base[i] + (int64_t)vox * p.lda + c;
             }
-            ra[i] = v;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(A + (ok ? off : 0));
+            ra[i] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        rb = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (tid < 128) {
+        {
+            bool ok;
+            int64_t off;
             if (p.b_layout == 0) {          // [N][K]: chunk (n = tid>>3, kc)
-                int n = tid >> 3;
-                if (kin && n < p.N) rb = *reinterpret_cast<const f32x4*>(B + (int64_t)n * p.ldb + k);
+                const int n = tid >> 3;
+                ok = tid < 128 && kin && n < p.N;
+                off = (int64_t)n * p.ldb + k;
             } else {                        // [K][N]: chunk (k = tid>>2, n4 = tid&3)
-                int kg = kt * BK + (tid >> 2), n = (tid & 3) * 4;
-                if (kg < p.K && n < p.N) rb = *reinterpret_cast<const f32x4*>(B + (int64_t)kg * p.ldb + n);
+                const int kg = kt * BK + (tid >> 2), n = (tid & 3) * 4;
+                ok = tid < 128 && kg < p.K && n < p.N;
+                off = (int64_t)kg * p.ldb + n;
             }
+            const f32x4 v = *reinterpret_cast<const f32x4*>(B + (ok ? off : 0));
+            rb = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
     auto store_tile = [&]() {
@@ -203,28 +207,27 @@ __global__ __launch_bounds__(256) void smallm_wgrad_kernel(WgradArgs p) {
     for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 ra, rb[8];
     auto load_tile = [&](int r0) {
-        ra = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (tid < 128) {
-            int row = r0 + arow;
-            if (row < r_end && am < p.M) ra = *reinterpret_cast<const f32x4*>(A + (int64_t)row * p.lda + am);
+        {
+            const int row = r0 + arow;
+            const bool ok = tid < 128 && row < r_end && am < p.M;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(A + (ok ? (int64_t)row * p.lda + am : 0));
+            ra = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         const int row = r0 + br;
         uint32_t n = 0, pk = 0;
         const bool rin = row < r_end;
-        if (rin && !p.g.is_gemm) decode_row((uint32_t)row, p.g, n, pk);
+        if (!p.g.is_gemm) decode_row((uint32_t)(rin ? row : 0), p.g, n, pk);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (rin && tapk[i] != 0xFFFFFFFFu) {
-                if (p.g.is_gemm) {
-                    v = *reinterpret_cast<const f32x4*>(B + (int64_t)row * p.ldb + cch[i]);
-                } else {
-                    int vox;
-                    if (gather_voxel(pk, (int)(tapk[i] >> 20), (int)((tapk[i] >> 10) & 1023), (int)(tapk[i] & 1023), p.g, vox))
-                        v = *reinterpret_cast<const f32x4*>(B + (int64_t)n * p.g.sample_pitch + (int64_t)vox * p.ldb + cch[i]);
-                }
+            bool ok = rin && tapk[i] != 0xFFFFFFFFu;
+            int64_t off = (int64_t)row * p.ldb + cch[i];
+            if (!p.g.is_gemm) {
+                int vox;
+                ok = gather_voxel(pk, (int)(tapk[i] >> 20), (int)((tapk[i] >> 10) & 1023), (int)(tapk[i] & 1023), p.g, vox) && ok;
+                off = (int64_t)n * p.g.sample_pitch + (int64_t)vox * p.ldb + cch[i];
             }
-            rb[i] = v;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(B + (ok ? off : 0));
+            rb[i] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
     auto store_tile = [&]() {

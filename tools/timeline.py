@@ -1,0 +1,40 @@
+"""Occupancy timeline from a rocprofv3 kernel trace: how much of the last step has an MFMA kernel running, only
+non-MFMA kernels running, or nothing running.  Usage: python tools/timeline.py <kernel_trace.csv> [step_ms]"""
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["Queue_Id"])) for r in rows]
+ev.sort()
+# find the last step: bce kernel marks the fwd/bwd boundary; take from the previous step's end.  Simpler: last `span` ms
+t_end = max(e[1] for e in ev)
+span = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else 345e6
+t0 = t_end - span
+ev = [e for e in ev if e[1] > t0]
+def is_mfma(n): return any(k in n for k in ("gemm_fwd_kernel", "wgrad_kernel", "conv3_patch", "smalln_fwd", "smallm_wgrad", "conv1x1_small"))
+pts = []
+for s, e, n, q in ev:
+    s = max(s, t0)
+    pts.append((s, 1, is_mfma(n))); pts.append((e, -1, is_mfma(n)))
+pts.sort()
+nm = no = 0; last = t0; acc = collections.Counter(); conc = collections.Counter()
+for t, d, m in pts:
+    dt = t - last
+    if dt > 0:
+        acc["mfma" if nm else ("other_only" if no else "idle")] += dt
+        conc[(nm, no)] += dt
+    last = t
+    if m: nm += d
+    else: no += d
+tot = sum(acc.values())
+for k, v in acc.items(): print("%-12s %8.1f ms  %.1f%%" % (k, v / 1e6, 100 * v / tot))
+print("concurrency (n_mfma, n_other) -> ms")
+for k, v in sorted(conc.items(), key=lambda kv: -kv[1])[:12]: print("  ", k, "%.1f" % (v / 1e6))
+# phases: bucket into 20 slices, list top kernels by busy time in each
+NB = 23
+for b in range(NB):
+    lo, hi = t0 + span * b / NB, t0 + span * (b + 1) / NB
+    c = collections.Counter()
+    for s, e, n, q in ev:
+        o = min(e, hi) - max(s, lo)
+        if o > 0: c[n.split("(")[0][:40]] += o
+    top = ", ".join("%s %.1f" % (k.replace("void ", ""), v / 1e6) for k, v in c.most_common(4))
+    print("[%5.0f-%5.0f ms] busy-sum %.1f : %s" % ((lo - t0) / 1e6, (hi - t0) / 1e6, sum(c.values()) / 1e6, top))
