@@ -21,7 +21,7 @@ struct PatchArgs {
     const float* Wp;                 // [nchunk][Co][27*CC]
     float* Y; int64_t ldy;
     const float* bias;
-    int B, Sd, Sh, Sw, Od, Oh, Ow, Ci, Co, pad, clamp;
+    int B, Sd, Sh, Sw, Od, Oh, Ow, Ci, Co, pad, clamp, ntiles, wres;
     int ltd, lth, ltw, ntd, nth, ntw;
     FastDiv dHW, dW;                 // patch voxel index -> (pd, ph, pw)
     FastDiv dT0, dT1, dT2;           // tile index -> (b, td, th, tw)
@@ -36,8 +36,13 @@ struct PatchCfg {
     static constexpr int NKG = KCP / 64;
 };
 
+// NA accumulator quads: NG output-channel groups, doubled (even / odd k) when NG <= 2 so that consecutive MFMAs never wait
+// for the result of the one two slots earlier (the 4x4x1 MFMA issues in 2 passes but its result takes longer).
+template <int NG>
+struct PatchAcc { static constexpr int NA = NG; };
+
 template <int NG, int CC, int KG, int Bk>
-__device__ __forceinline__ void patch_mfma_step(f32x4 (&acc)[NG], const f32x4 (&wreg)[NG], const float* __restrict__ patch, int pvoff,
+__device__ __forceinline__ void patch_mfma_step(f32x4 (&acc)[PatchAcc<NG>::NA], const f32x4 (&wreg)[NG], const float* __restrict__ patch, int pvoff,
                                                 int PH, int PW) {
     constexpr int kidx = KG * 64 + Bk * 4;
     if constexpr (kidx < 27 * CC) {
@@ -48,11 +53,15 @@ __device__ __forceinline__ void patch_mfma_step(f32x4 (&acc)[NG], const f32x4 (&
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[g][e], x4[e], acc[g], 4, Bk, 0);
+            for (int g = 0; g < NG; ++g) {
+                constexpr int NA = PatchAcc<NG>::NA;
+                const int a = NA == NG ? g : (e & 1) * NG + g;
+                acc[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[g][e], x4[e], acc[a], 4, Bk, 0);
+            }
     }
 }
 template <int NG, int CC, int KG, int... Bs>
-__device__ __forceinline__ void patch_kgroup(f32x4 (&acc)[NG], const float* __restrict__ wl, const float* __restrict__ patch, int pvoff,
+__device__ __forceinline__ void patch_kgroup(f32x4 (&acc)[PatchAcc<NG>::NA], const float* __restrict__ wl, const float* __restrict__ patch, int pvoff,
                                              int PH, int PW, int lane, std::integer_sequence<int, Bs...>) {
     using Cfg = PatchCfg<NG, CC>;
     f32x4 wreg[NG];
@@ -61,119 +70,186 @@ __device__ __forceinline__ void patch_kgroup(f32x4 (&acc)[NG], const float* __re
     (patch_mfma_step<NG, CC, KG, Bs>(acc, wreg, patch, pvoff, PH, PW), ...);
 }
 template <int NG, int CC, int... KGs>
-__device__ __forceinline__ void patch_chunk(f32x4 (&acc)[NG], const float* __restrict__ wl, const float* __restrict__ patch, int pvoff,
+__device__ __forceinline__ void patch_chunk(f32x4 (&acc)[PatchAcc<NG>::NA], const float* __restrict__ wl, const float* __restrict__ patch, int pvoff,
                                             int PH, int PW, int lane, std::integer_sequence<int, KGs...>) {
     (patch_kgroup<NG, CC, KGs>(acc, wl, patch, pvoff, PH, PW, lane, std::make_integer_sequence<int, 16>{}), ...);
 }
 
-template <int NG, int CC>
+// Persistent workgroups walk a contiguous range of tiles (neighbouring tiles share their halo through L2).  The work list
+// is the sequence of (tile, channel chunk) items; while the MFMAs of item i run, the global loads of item i+1 (halo'd patch
+// and, when there is more than one chunk, its weights) are already in flight into registers, so staging costs only the LDS
+// stores and two barriers instead of exposed HBM/L2 round trips.  Loads are unconditional from the clamped voxel (always
+// mapped) and zero padding is applied at the LDS store: a load under a branch makes the compiler drain vmcnt at the join.
+// NPF = halo float4 per thread: ceil(648 * CC/4 / 256) for the usual 4 x 4 x 16 tile, ceil(972 * ...) for the shallow-grid tiles.
+template <int NG, int CC, int NPF>
 __global__ __launch_bounds__(256) void conv3_patch_kernel(PatchArgs p) {
     using Cfg = PatchCfg<NG, CC>;
+    constexpr int C4 = CC / 4;
+    constexpr int K4 = Cfg::KC / 4;
+    constexpr int NWF = (4 * NG * K4 + 255) / 256;        // weight float4 per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TD = 1 << p.ltd, TH = 1 << p.lth, TW = 1 << p.ltw;
     const int PD = TD + 2, PH = TH + 2, PW = TW + 2;
     const int NPV = PD * PH * PW;
     float* wl = smem;                                   // [4*NG][WP]
-    float* patch = smem + 4 * NG * Cfg::WP;             // [NPV][CP]
+    float* patch = smem + (p.wres ? p.Ci / CC : 1) * 4 * NG * Cfg::WP;      // [NPV][CP]
+    float* biasl = patch + NPV * Cfg::CP;               // [4*NG]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // tile -> (b, td, th, tw)
-    uint32_t t = blockIdx.x;
-    const uint32_t b = fdiv(t, p.dT0);
-    t -= b * p.dT0.d;
-    const uint32_t itd = fdiv(t, p.dT1);
-    t -= itd * p.dT1.d;
-    const uint32_t ith = fdiv(t, p.dT2);
-    const uint32_t itw = t - ith * p.dT2.d;
-    const int od0 = itd << p.ltd, oh0 = ith << p.lth, ow0 = itw << p.ltw;
-
+    if (tid < 4 * NG) biasl[tid] = (p.bias && tid < p.Co) ? p.bias[tid] : 0.f;
     // this lane's voxel inside the tile
     const int lv = wave * 64 + lane;
     const int vw = lv & (TW - 1), vh = (lv >> p.ltw) & (TH - 1), vd = lv >> (p.ltw + p.lth);
     const int pvoff = (vd * PH + vh) * PW + vw;
 
-    f32x4 acc[NG];
+    // tile-independent staging roles of this thread: patch item u -> halo voxel (pd, ph, pw), channel quad, LDS offset
+    const int total = NPV * C4;
+    uint32_t pcoord[NPF];
+    int pdst[NPF];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < NPF; ++u) {
+        const int i = tid + u * 256;
+        const int ic = min(i, total - 1);
+        const int pv = ic / C4, c4 = ic - pv * C4;
+        const uint32_t pd = fdiv((uint32_t)pv, p.dHW);
+        const uint32_t rem = pv - pd * p.dHW.d;
+        const uint32_t ph = fdiv(rem, p.dW);
+        const uint32_t pw = rem - ph * p.dW.d;
+        pcoord[u] = (pd << 24) | (ph << 16) | (pw << 8) | (uint32_t)c4;
+        pdst[u] = i < total ? pv * Cfg::CP + c4 * 4 : -1;
+    }
+    const int nw = p.Co * K4;                            // weight float4 of one chunk
+    const int nchunk = p.Ci / CC;
+    const int nwl = p.wres ? nchunk : 1;                 // weight chunks resident in LDS (all of them when they fit beside the patch)
 
     // zero the weight rows/tails that are never overwritten
-    for (int i = tid; i < 4 * NG * Cfg::WP; i += 256) wl[i] = 0.f;
-
-    const float* __restrict__ Xb = p.X + (int64_t)b * p.Sd * p.Sh * p.Sw * p.ldx;
-    const int nchunk = p.Ci / CC;
-    for (int ch = 0; ch < nchunk; ++ch) {
-        __syncthreads();                                 // previous chunk's readers are done (and the zero fill is visible)
-        // ---- stage weights of this chunk: Co rows x KC floats
-        {
-            constexpr int K4 = Cfg::KC / 4;
-            const float* __restrict__ wsrc = p.Wp + (int64_t)ch * p.Co * Cfg::KC;
-            for (int i = tid; i < p.Co * K4; i += 256) {
+    for (int i = tid; i < nwl * 4 * NG * Cfg::WP; i += 256) wl[i] = 0.f;
+    if (p.wres) {
+        __syncthreads();
+        for (int c = 0; c < nchunk; ++c)
+            for (int i = tid; i < nw; i += 256) {
                 const int co = i / K4, kk = i - co * K4;
-                *reinterpret_cast<f32x4*>(wl + co * Cfg::WP + kk * 4) = *reinterpret_cast<const f32x4*>(wsrc + (int64_t)co * Cfg::KC + kk * 4);
+                *reinterpret_cast<f32x4*>(wl + (c * 4 * NG + co) * Cfg::WP + kk * 4) =
+                    *reinterpret_cast<const f32x4*>(p.Wp + ((int64_t)c * p.Co * K4 + i) * 4);
             }
+    }
+
+    const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t_begin = (int)blockIdx.x * per, t_end = min(p.ntiles, t_begin + per);
+    const int nitems = max(t_end - t_begin, 0) * nchunk;
+
+    f32x4 pre[NPF], wpre[NWF];
+    uint32_t zmask = 0;
+    auto issue = [&](int tile, int ch, bool with_w) {
+        uint32_t t = (uint32_t)tile;
+        const uint32_t b = fdiv(t, p.dT0);
+        t -= b * p.dT0.d;
+        const uint32_t itd = fdiv(t, p.dT1);
+        t -= itd * p.dT1.d;
+        const uint32_t ith = fdiv(t, p.dT2);
+        const uint32_t itw = t - ith * p.dT2.d;
+        const int od0 = (int)(itd << p.ltd) - p.pad, oh0 = (int)(ith << p.lth) - p.pad, ow0 = (int)(itw << p.ltw) - p.pad;
+        const float* __restrict__ Xb = p.X + (int64_t)b * p.Sd * p.Sh * p.Sw * p.ldx + ch * CC;
+        zmask = 0;
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int sd = od0 + (int)(pcoord[u] >> 24), sh = oh0 + (int)((pcoord[u] >> 16) & 255), sw = ow0 + (int)((pcoord[u] >> 8) & 255);
+            const int cd = min(max(sd, 0), p.Sd - 1), chh = min(max(sh, 0), p.Sh - 1), cw = min(max(sw, 0), p.Sw - 1);
+            zmask |= (uint32_t)(!p.clamp && (cd != sd || chh != sh || cw != sw)) << u;
+            pre[u] = *reinterpret_cast<const f32x4*>(Xb + ((int64_t)(cd * p.Sh + chh) * p.Sw + cw) * p.ldx + (pcoord[u] & 255) * 4);
         }
-        // ---- stage the halo'd input patch of this channel chunk; loads are issued in batches of 8 per thread so that
-        //      their latencies overlap (a load -> wait -> ds_write loop is bound by 14 serial HBM round trips).  The loads are
-        //      unconditional from the clamped voxel (always mapped) and zero padding is applied at the LDS store: a load under a
-        //      branch makes the compiler drain vmcnt at the join.
-        {
-            constexpr int C4 = CC / 4, UB = 8;
-            const int total = NPV * C4;
-            for (int i0 = tid; i0 < total; i0 += 256 * UB) {
-                f32x4 v[UB];
-                int dst[UB];
-                bool zf[UB];
+        if (with_w) {
+            const float* __restrict__ wsrc = p.Wp + (int64_t)ch * p.Co * Cfg::KC;
 #pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    const int i = i0 + u * 256;
-                    const int ic = min(i, total - 1);
-                    const int pv = ic / C4, c4 = ic - pv * C4;
-                    const uint32_t pd = fdiv((uint32_t)pv, p.dHW);
-                    const uint32_t rem = pv - pd * p.dHW.d;
-                    const uint32_t ph = fdiv(rem, p.dW);
-                    const uint32_t pw = rem - ph * p.dW.d;
-                    const int sd = od0 + (int)pd - p.pad, sh = oh0 + (int)ph - p.pad, sw = ow0 + (int)pw - p.pad;
-                    const int cd = min(max(sd, 0), p.Sd - 1), chh = min(max(sh, 0), p.Sh - 1), cw = min(max(sw, 0), p.Sw - 1);
-                    zf[u] = !p.clamp && (cd != sd || chh != sh || cw != sw);
-                    dst[u] = i < total ? pv * Cfg::CP + c4 * 4 : -1;
-                    v[u] = *reinterpret_cast<const f32x4*>(Xb + ((int64_t)(cd * p.Sh + chh) * p.Sw + cw) * p.ldx + ch * CC + c4 * 4);
+            for (int u = 0; u < NWF; ++u) wpre[u] = *reinterpret_cast<const f32x4*>(wsrc + (int64_t)min(tid + u * 256, nw - 1) * 4);
+        }
+    };
+
+    constexpr int NA = PatchAcc<NG>::NA;
+    f32x4 acc[NA];
+#pragma unroll
+    for (int g = 0; g < NA; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nitems > 0) issue(t_begin, 0, !p.wres);
+    int tile = t_begin, ch = 0;
+    for (int it = 0; it < nitems; ++it) {
+        __syncthreads();                                 // the previous item's readers are done (and the zero fill is visible)
+#pragma unroll
+        for (int u = 0; u < NPF; ++u)
+            if (pdst[u] >= 0) *reinterpret_cast<f32x4*>(patch + pdst[u]) = (zmask >> u) & 1 ? (f32x4){0.f, 0.f, 0.f, 0.f} : pre[u];
+        if (!p.wres && (it == 0 || nchunk > 1)) {        // a single chunk's weights stay resident for all tiles
+#pragma unroll
+            for (int u = 0; u < NWF; ++u) {
+                const int i = tid + u * 256;
+                if (i < nw) {
+                    const int co = i / K4, kk = i - co * K4;
+                    *reinterpret_cast<f32x4*>(wl + co * Cfg::WP + kk * 4) = wpre[u];
                 }
-#pragma unroll
-                for (int u = 0; u < UB; ++u)
-                    if (dst[u] >= 0) *reinterpret_cast<f32x4*>(patch + dst[u]) = zf[u] ? (f32x4){0.f, 0.f, 0.f, 0.f} : v[u];
             }
         }
         __syncthreads();
-        patch_chunk<NG, CC>(acc, wl, patch, pvoff, PH, PW, lane, std::make_integer_sequence<int, Cfg::NKG>{});
-    }
-
-    const int od = od0 + vd, oh = oh0 + vh, ow = ow0 + vw;
-    if (od < p.Od && oh < p.Oh && ow < p.Ow) {
-        const int64_t row = (((int64_t)b * p.Od + od) * p.Oh + oh) * p.Ow + ow;
+        int ntile = tile, nch = ch + 1;
+        if (nch == nchunk) { nch = 0; ++ntile; }
+        if (it + 1 < nitems) issue(ntile, nch, !p.wres && nchunk > 1);      // in flight during the MFMAs below
+        patch_chunk<NG, CC>(acc, wl + (p.wres ? ch : 0) * 4 * NG * Cfg::WP, patch, pvoff, PH, PW, lane, std::make_integer_sequence<int, Cfg::NKG>{});
+        if (ch == nchunk - 1) {
+            uint32_t t = (uint32_t)tile;
+            const uint32_t b = fdiv(t, p.dT0);
+            t -= b * p.dT0.d;
+            const uint32_t itd = fdiv(t, p.dT1);
+            t -= itd * p.dT1.d;
+            const uint32_t ith = fdiv(t, p.dT2);
+            const uint32_t itw = t - ith * p.dT2.d;
+            const int od = (int)(itd << p.ltd) + vd, oh = (int)(ith << p.lth) + vh, ow = (int)(itw << p.ltw) + vw;
+            if (od < p.Od && oh < p.Oh && ow < p.Ow) {
+                const int64_t row = (((int64_t)b * p.Od + od) * p.Oh + oh) * p.Ow + ow;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g * 4 >= p.Co) continue;
-            f32x4 v = acc[g];
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + g * 4);
-            *reinterpret_cast<f32x4*>(p.Y + row * p.ldy + g * 4) = v;
+                for (int g = 0; g < NG; ++g) {
+                    if (g * 4 >= p.Co) continue;
+                    f32x4 v = acc[g];
+                    if constexpr (NA != NG) v += acc[NG + g];
+                    v += *reinterpret_cast<const f32x4*>(biasl + g * 4);       // LDS copy: a global load here would wait for the prefetch in flight
+                    *reinterpret_cast<f32x4*>(p.Y + row * p.ldy + g * 4) = v;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < NA; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+        tile = ntile;
+        ch = nch;
     }
 }
 
-template <int NG, int CC>
-static int launch_patch(const PatchArgs& a, unsigned tiles, size_t lds, hipStream_t s) {
+template <int NG, int CC, int NPF>
+static int launch_patch_npf(const PatchArgs& a, unsigned tiles, size_t lds, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_patch_kernel<NG, CC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_patch_kernel<NG, CC, NPF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess) {
             (void)hipGetLastError();
             return CORRIF_ELAUNCH;
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3_patch_kernel<NG, CC>), dim3(tiles), dim3(256), lds, s, a);
+    const unsigned per_cu = lds > 80 * 1024 ? 1 : 2;                     // co-resident workgroups per CU (LDS bound)
+    const unsigned grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
+    hipLaunchKernelGGL((conv3_patch_kernel<NG, CC, NPF>), dim3(grid), dim3(256), lds, s, a);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
+}
+template <int NG, int CC>
+static int launch_patch(const PatchArgs& a, unsigned tiles, int npv, hipStream_t s) {
+    using Cfg = PatchCfg<NG, CC>;
+    PatchArgs b = a;
+    const int nchunk = a.Ci / CC;
+    const size_t fixed = (size_t)(npv * Cfg::CP + 4 * NG) * sizeof(float), wchunk = (size_t)4 * NG * Cfg::WP * sizeof(float);
+    b.wres = nchunk > 1 && fixed + nchunk * wchunk <= 80 * 1024;         // all weight chunks resident while two workgroups still share a CU
+    const size_t lds = fixed + (b.wres ? nchunk : 1) * wchunk;
+    if (lds > 160 * 1024) return CORRIF_EUNSUPPORTED;
+    constexpr int C4 = CC / 4, NPF_STD = (648 * C4 + 255) / 256, NPF_MAX = (972 * C4 + 255) / 256;
+    if (npv * C4 <= NPF_STD * 256) return launch_patch_npf<NG, CC, NPF_STD>(b, tiles, lds, s);
+    if (npv * C4 <= NPF_MAX * 256) return launch_patch_npf<NG, CC, NPF_MAX>(b, tiles, lds, s);
+    return CORRIF_EUNSUPPORTED;
 }
 
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
@@ -210,15 +286,12 @@ extern "C" int corrif_conv3_patch(const CorrifConv3Patch* q, void* stream) {
     a.dT2 = make_fastdiv((uint32_t)a.ntw);
     const int64_t tiles = (int64_t)q->B * a.ntd * a.nth * a.ntw;
     if (tiles <= 0 || tiles >= ((int64_t)1 << 31)) return CORRIF_EUNSUPPORTED;
+    a.ntiles = (int)tiles;
     const int NG = (q->Co + 3) / 4;
     const int NPV = PD * PH * PW;
     hipStream_t s = (hipStream_t)stream;
-#define PATCH_CASE(ng, cc)                                                                                         \
-    if (NG == ng && CC == cc) {                                                                                    \
-        size_t lds = (size_t)(4 * ng * PatchCfg<ng, cc>::WP + NPV * PatchCfg<ng, cc>::CP) * sizeof(float);         \
-        if (lds > 160 * 1024) return CORRIF_EUNSUPPORTED;                                                          \
-        return launch_patch<ng, cc>(a, (unsigned)tiles, lds, s);                                                   \
-    }
+#define PATCH_CASE(ng, cc) \
+    if (NG == ng && CC == cc) return launch_patch<ng, cc>(a, (unsigned)tiles, NPV, s);
     PATCH_CASE(1, 16) PATCH_CASE(2, 16) PATCH_CASE(1, 8) PATCH_CASE(2, 8) PATCH_CASE(3, 8) PATCH_CASE(4, 8) PATCH_CASE(5, 8)
     PATCH_CASE(6, 8) PATCH_CASE(7, 8) PATCH_CASE(8, 8)
 #undef PATCH_CASE
@@ -259,9 +332,10 @@ __device__ __forceinline__ void wg_cgroup(f32x4 (&a)[NG], const float (&areg)[NG
     (wg_step<NG, VBs>(a, areg, xaddr), ...);
 }
 
-template <int NG, int NCH>
+template <int NG, int NCH, int NPF>
 __global__ __launch_bounds__(256, 2) void conv3_patch_wgrad_kernel(PatchWgArgs p) {
     constexpr int CC = 16, CP = 16, TW = 16, PW = TW + 2, DP = 4 * NG + 4, KC = 27 * CC;   // CP = 16: taps 1 apart in w sit 16 banks apart
+    constexpr int C4 = CC / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TD = 1 << p.ltd, TH = 1 << p.lth, PH = TH + 2;
     const int NPV = (TD + 2) * PH * PW;
@@ -289,59 +363,121 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_wgrad_kernel(PatchWgArgs p
 #pragma unroll
             for (int g = 0; g < NG; ++g) acc[c][cg][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-        uint32_t t = tile;
-        const uint32_t b = fdiv(t, p.dT0);
+    // halo item i = tid + 256 u -> (halo voxel pv, channel quad c4); decoded on the fly (the accumulators leave no registers
+    // to keep the decoded coordinates of every item)
+    const int total = NPV * C4;
+    // The loads of the next (tile, chunk) item fly while the MFMAs of the current one run; staging costs only the LDS stores.
+    f32x4 pre[NPF], dpre[NG];
+    uint32_t zmask = 0, dmask = 0;
+    auto tile_origin = [&](int tile, uint32_t& b, int& od0, int& oh0, int& ow0) {
+        uint32_t t = (uint32_t)tile;
+        b = fdiv(t, p.dT0);
         t -= b * p.dT0.d;
         const uint32_t itd = fdiv(t, p.dT1);
         t -= itd * p.dT1.d;
         const uint32_t ith = fdiv(t, p.dT2);
         const uint32_t itw = t - ith * p.dT2.d;
-        const int od0 = itd << p.ltd, oh0 = ith << p.lth, ow0 = itw * TW;
-        __syncthreads();                                        // previous tile's readers are done
-        {   // ---- dY tile: voxel v = (vd*TH + vh)*16 + vw
-            const float* __restrict__ gb = p.DY + (int64_t)b * p.Od * p.Oh * p.Ow * p.lddy;
-            for (int i = tid; i < 256 * NG; i += 256) {
-                const int v = i / NG, g = i - v * NG;
-                const int vw = v & 15, vh = (v >> 4) & (TH - 1), vd = v >> (4 + p.lth);
-                const int od = od0 + vd, oh = oh0 + vh, ow = ow0 + vw;
-                const bool ok = od < p.Od && oh < p.Oh && ow < p.Ow && g * 4 < p.Co;
-                const f32x4 val = *reinterpret_cast<const f32x4*>(gb + (ok ? ((int64_t)(od * p.Oh + oh) * p.Ow + ow) * p.lddy + g * 4 : 0));
-                *reinterpret_cast<f32x4*>(dys + v * DP + g * 4) = ok ? val : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+        od0 = (int)(itd << p.ltd); oh0 = (int)(ith << p.lth); ow0 = (int)itw * TW;
+    };
+    auto issue_patch = [&](int tile, int ch) {
+        uint32_t b;
+        int od0, oh0, ow0;
+        tile_origin(tile, b, od0, oh0, ow0);
+        const float* __restrict__ xb = p.X + (int64_t)b * p.Sd * p.Sh * p.Sw * p.ldx + c_lo + ch * CC;
+        zmask = 0;
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int ic = min(tid + u * 256, total - 1);
+            const int pv = ic >> 2, c4 = ic & 3;
+            const uint32_t pd = fdiv((uint32_t)pv, p.dHW);
+            const uint32_t rem = pv - pd * p.dHW.d;
+            const uint32_t ph = fdiv(rem, p.dW);
+            const uint32_t pw = rem - ph * p.dW.d;
+            const int sd = od0 - p.pad + (int)pd, sh = oh0 - p.pad + (int)ph, sw = ow0 - p.pad + (int)pw;
+            const int cd = min(max(sd, 0), p.Sd - 1), chh = min(max(sh, 0), p.Sh - 1), cw = min(max(sw, 0), p.Sw - 1);
+            zmask |= (uint32_t)(!p.clamp && (cd != sd || chh != sh || cw != sw)) << u;
+            pre[u] = *reinterpret_cast<const f32x4*>(xb + ((int64_t)(cd * p.Sh + chh) * p.Sw + cw) * p.ldx + c4 * 4);
         }
-        const float* __restrict__ xb = p.X + (int64_t)b * p.Sd * p.Sh * p.Sw * p.ldx;
+    };
+    auto stage_direct = [&](int tile, int ch) {      // no prefetch: batches of 4 loads -> LDS stores
+        uint32_t b;
+        int od0, oh0, ow0;
+        tile_origin(tile, b, od0, oh0, ow0);
+        const float* __restrict__ xb = p.X + (int64_t)b * p.Sd * p.Sh * p.Sw * p.ldx + c_lo + ch * CC;
+        for (int i0 = tid; i0 < total; i0 += 256 * 4) {
+            f32x4 v[4];
+            bool zf[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ic = min(i0 + u * 256, total - 1);
+                const int pv = ic >> 2, c4 = ic & 3;
+                const uint32_t pd = fdiv((uint32_t)pv, p.dHW);
+                const uint32_t rem = pv - pd * p.dHW.d;
+                const uint32_t ph = fdiv(rem, p.dW);
+                const uint32_t pw = rem - ph * p.dW.d;
+                const int sd = od0 - p.pad + (int)pd, sh = oh0 - p.pad + (int)ph, sw = ow0 - p.pad + (int)pw;
+                const int cd = min(max(sd, 0), p.Sd - 1), chh = min(max(sh, 0), p.Sh - 1), cw = min(max(sw, 0), p.Sw - 1);
+                zf[u] = !p.clamp && (cd != sd || chh != sh || cw != sw);
+                v[u] = *reinterpret_cast<const f32x4*>(xb + ((int64_t)(cd * p.Sh + chh) * p.Sw + cw) * p.ldx + c4 * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * 256 < total) *reinterpret_cast<f32x4*>(patch + (i0 + u * 256) * 4) = zf[u] ? (f32x4){0.f, 0.f, 0.f, 0.f} : v[u];
+        }
+    };
+    auto issue_dy = [&](int tile) {      // dY tile: voxel v = (vd*TH + vh)*16 + vw, item i = v*NG + g
+        uint32_t b;
+        int od0, oh0, ow0;
+        tile_origin(tile, b, od0, oh0, ow0);
+        const float* __restrict__ gb = p.DY + (int64_t)b * p.Od * p.Oh * p.Ow * p.lddy;
+        dmask = 0;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int i = tid + 256 * j;
+            const int v = i / NG, g = i - v * NG;
+            const int vw = v & 15, vh = (v >> 4) & (TH - 1), vd = v >> (4 + p.lth);
+            const int od = od0 + vd, oh = oh0 + vh, ow = ow0 + vw;
+            const bool ok = od < p.Od && oh < p.Oh && ow < p.Ow && g * 4 < p.Co;
+            dpre[j] = *reinterpret_cast<const f32x4*>(gb + (ok ? ((int64_t)(od * p.Oh + oh) * p.Ow + ow) * p.lddy + g * 4 : 0));
+            dmask |= (uint32_t)ok << j;
+        }
+    };
+
+    // NG >= 3: the accumulators (28 NG registers) leave no room to hold the next item across the MFMA section without spilling,
+    // so those variants load right before the LDS stores (two workgroups per CU still overlap each other's staging).
+    constexpr bool PF = NG <= 2;
+    int tile = blockIdx.x;
+    if (PF && tile < p.ntiles) { issue_patch(tile, 0); issue_dy(tile); }
+    for (; tile < p.ntiles; tile += gridDim.x) {
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-            if (ch > 0) __syncthreads();                        // the previous chunk's patch is no longer read
-            {   // ---- halo'd X patch of this 16-channel chunk (batched loads)
-                constexpr int C4 = CC / 4, UB = 4;
-                const int total = NPV * C4;
-                for (int i0 = tid; i0 < total; i0 += 256 * UB) {
-                    f32x4 v[UB];
-                    int dst[UB];
-                    bool zf[UB];
+            __syncthreads();                                    // the previous item's readers are done
+            if constexpr (!PF) {
+                stage_direct(tile, ch);
+                if (ch == 0) issue_dy(tile);
+            }
 #pragma unroll
-                    for (int u = 0; u < UB; ++u) {
-                        const int i = i0 + u * 256;
-                        const int ic = min(i, total - 1);          // unconditional clamped loads, zero fill at the LDS store (see the forward kernel)
-                        const int pv = ic / C4, c4 = ic - pv * C4;
-                        const uint32_t pd = fdiv((uint32_t)pv, p.dHW);
-                        const uint32_t rem = pv - pd * p.dHW.d;
-                        const uint32_t ph = fdiv(rem, p.dW);
-                        const uint32_t pw = rem - ph * p.dW.d;
-                        const int sd = od0 + (int)pd - p.pad, sh = oh0 + (int)ph - p.pad, sw = ow0 + (int)pw - p.pad;
-                        const int cd = min(max(sd, 0), p.Sd - 1), chh = min(max(sh, 0), p.Sh - 1), cw = min(max(sw, 0), p.Sw - 1);
-                        zf[u] = !p.clamp && (cd != sd || chh != sh || cw != sw);
-                        dst[u] = i < total ? pv * CP + c4 * 4 : -1;
-                        v[u] = *reinterpret_cast<const f32x4*>(xb + ((int64_t)(cd * p.Sh + chh) * p.Sw + cw) * p.ldx + c_lo + ch * CC + c4 * 4);
-                    }
+            for (int u = 0; u < (PF ? NPF : 0); ++u) {      // CP == CC: the patch is item-linear
+                const int i = tid + u * 256;
+                if (i < total) *reinterpret_cast<f32x4*>(patch + i * 4) = (zmask >> u) & 1 ? (f32x4){0.f, 0.f, 0.f, 0.f} : pre[u];
+            }
+            if (ch == 0) {
 #pragma unroll
-                    for (int u = 0; u < UB; ++u)
-                        if (dst[u] >= 0) *reinterpret_cast<f32x4*>(patch + dst[u]) = zf[u] ? (f32x4){0.f, 0.f, 0.f, 0.f} : v[u];
+                for (int j = 0; j < NG; ++j) {
+                    const int i = tid + 256 * j;
+                    const int v = i / NG, g = i - v * NG;
+                    *reinterpret_cast<f32x4*>(dys + v * DP + g * 4) = (dmask >> j) & 1 ? dpre[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             }
             __syncthreads();
+            if constexpr (PF) {
+                if (ch + 1 < NCH) {
+                    issue_patch(tile, ch + 1);
+                } else if (tile + (int)gridDim.x < p.ntiles) {
+                    issue_patch(tile + (int)gridDim.x, 0);
+                    issue_dy(tile + (int)gridDim.x);
+                }
+            }
             // ---- this wave's 64 voxels = 4 w-rows of 16
             for (int vq = 0; vq < 4; ++vq) {
                 const int r = wave * 4 + vq;                    // w-row inside the tile
@@ -377,8 +513,7 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_wgrad_kernel(PatchWgArgs p
 
 static void wg_cfg(int Ci, int Co, int& NG, int& NCH, int& nz, int& wgs) {
     NG = (Co + 3) / 4;
-    NCH = NG == 1 ? 4 : (NG == 2 ? 2 : 1);
-    while (NCH > 1 && (Ci % (16 * NCH))) NCH >>= 1;
+    NCH = 1;        // one 16-channel chunk per workgroup: with the next item prefetched in registers there is no room for more accumulators
     nz = Ci / (16 * NCH);
     wgs = 512 / nz;
     if (wgs < 1) wgs = 1;
@@ -393,20 +528,27 @@ extern "C" size_t corrif_conv3_patch_wgrad_workspace(int32_t Ci, int32_t Co) {
     return (size_t)corrif_conv3_patch_wgrad_slots(Ci, Co) * Co * 27 * Ci * sizeof(float);
 }
 
-template <int NG, int NCH>
-static int launch_wg(const PatchWgArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+template <int NG, int NCH, int NPF>
+static int launch_wg_npf(const PatchWgArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     static bool done = false;
     if (!done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_patch_wgrad_kernel<NG, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_patch_wgrad_kernel<NG, NCH, NPF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess) {
             (void)hipGetLastError();
             return CORRIF_ELAUNCH;
         }
         done = true;
     }
-    hipLaunchKernelGGL((conv3_patch_wgrad_kernel<NG, NCH>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv3_patch_wgrad_kernel<NG, NCH, NPF>), grid, dim3(256), lds, s, a);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
+}
+template <int NG, int NCH>
+static int launch_wg(const PatchWgArgs& a, dim3 grid, size_t lds, int npv, hipStream_t s) {
+    constexpr int NPF_STD = (648 * 4 + 255) / 256, NPF_MAX = (972 * 4 + 255) / 256;     // halo float4 per thread (16-channel chunks)
+    if (npv * 4 <= NPF_STD * 256) return launch_wg_npf<NG, NCH, NPF_STD>(a, grid, lds, s);
+    if (npv * 4 <= NPF_MAX * 256) return launch_wg_npf<NG, NCH, NPF_MAX>(a, grid, lds, s);
+    return CORRIF_EUNSUPPORTED;
 }
 
 extern "C" int corrif_conv3_patch_wgrad(const CorrifConv3PatchWgrad* q, void* stream) {
@@ -438,13 +580,14 @@ extern "C" int corrif_conv3_patch_wgrad(const CorrifConv3PatchWgrad* q, void* st
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(wgs, 1, nz);          // slabs of workgroups that own no tile stay zero: the kernel still writes them
     int rc = CORRIF_EUNSUPPORTED;
-    if (NG == 1 && NCH == 4) rc = launch_wg<1, 4>(a, grid, lds, s);
-    else if (NG == 1 && NCH == 2) rc = launch_wg<1, 2>(a, grid, lds, s);
-    else if (NG == 1 && NCH == 1) rc = launch_wg<1, 1>(a, grid, lds, s);
-    else if (NG == 2 && NCH == 2) rc = launch_wg<2, 2>(a, grid, lds, s);
-    else if (NG == 2 && NCH == 1) rc = launch_wg<2, 1>(a, grid, lds, s);
-    else if (NG == 3) rc = launch_wg<3, 1>(a, grid, lds, s);
-    else if (NG == 4) rc = launch_wg<4, 1>(a, grid, lds, s);
+    const int npv = (TD + 2) * PH * 18;
+    if (NG == 1 && NCH == 4) rc = launch_wg<1, 4>(a, grid, lds, npv, s);
+    else if (NG == 1 && NCH == 2) rc = launch_wg<1, 2>(a, grid, lds, npv, s);
+    else if (NG == 1 && NCH == 1) rc = launch_wg<1, 1>(a, grid, lds, npv, s);
+    else if (NG == 2 && NCH == 2) rc = launch_wg<2, 2>(a, grid, lds, npv, s);
+    else if (NG == 2 && NCH == 1) rc = launch_wg<2, 1>(a, grid, lds, npv, s);
+    else if (NG == 3) rc = launch_wg<3, 1>(a, grid, lds, npv, s);
+    else if (NG == 4) rc = launch_wg<4, 1>(a, grid, lds, npv, s);
     if (rc != CORRIF_OK) return rc;
     return corrif_slab_reduce(q->ws, q->dW, (int64_t)q->Co * 27 * q->Ci, wgs * 4, stream);
 }

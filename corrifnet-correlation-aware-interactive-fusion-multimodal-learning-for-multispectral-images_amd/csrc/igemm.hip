@@ -21,7 +21,9 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
     constexpr int AI = BM / 32, BI = BN / 32;      // float4 chunks per thread per K tile
     // one LDS array: [A tile | B tile] during the K loop, re-used as the per-wave output staging area in the epilogue
     constexpr int SP = TN * 32 + 4;                       // staging row pitch (floats)
-    constexpr int LDS_FLOATS = (BM + BN) * LDS_PITCH > 4 * 32 * SP ? (BM + BN) * LDS_PITCH : 4 * 32 * SP;
+    constexpr int PBT = BN + 4;                           // row pitch of the K-major B tile (BL == 1)
+    constexpr int B_FLOATS = BL == 0 ? BN * LDS_PITCH : BK * PBT;
+    constexpr int LDS_FLOATS = BM * LDS_PITCH + B_FLOATS > 4 * 32 * SP ? BM * LDS_PITCH + B_FLOATS : 4 * 32 * SP;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     float* const As = lds;
     float* const Bs = lds + BM * LDS_PITCH;
@@ -169,14 +171,14 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(ar + 32 * i) * LDS_PITCH + kc * 4]) = (okB >> i) & 1 ? rb[i] : zero4;
         } else {
+            // [K][N] operand: the LDS tile stays K-major ([32][BN + 4], float4 stores without bank conflicts); the MFMA B
+            // fragments are then 4 ds_read_b32 per 8 k instead of one ds_read_b128 (a transposing scalar store was 8-way conflicted)
             constexpr int CN = BN / 4;
 #pragma unroll
             for (int i = 0; i < BI; ++i) {
                 int cidx = tid + 256 * i;
                 int nc = cidx % CN, kk = cidx / CN;
-                const f32x4 v = (okB >> i) & 1 ? rb[i] : zero4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) Bs[(nc * 4 + e) * LDS_PITCH + kk] = v[e];
+                *reinterpret_cast<f32x4*>(&Bs[kk * PBT + nc * 4]) = (okB >> i) & 1 ? rb[i] : zero4;
             }
         }
     };
@@ -194,8 +196,14 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
             for (int i = 0; i < TM; ++i)
                 a[i] = *reinterpret_cast<const f32x4*>(&As[((wm * TM + i) * 32 + frow) * LDS_PITCH + kk * 8 + fk]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * TN + j) * 32 + frow) * LDS_PITCH + kk * 8 + fk]);
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (BL == 0) {
+                    b[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * TN + j) * 32 + frow) * LDS_PITCH + kk * 8 + fk]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[j][e] = Bs[(kk * 8 + fk + e) * PBT + (wn * TN + j) * 32 + frow];
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll

@@ -15,7 +15,9 @@ for (M, N, K) in [(4096, 4096, 4096), (25088, 1024, 256), (25088, 256, 1024), (4
     A = torch.randn(M, K, device=dev); B = torch.randn(N, K, device=dev); C = torch.empty(M, N, device=dev)
     ms = bench(lambda: ops.gemm(A.data_ptr(), K, B.data_ptr(), K, 0, C.data_ptr(), N, M, N, K, K, H.gemm_geom()))
     print("gemm  M %7d N %5d K %5d : %8.3f ms  %6.1f TF/s" % (M, N, K, ms, 2.0 * M * N * K / ms / 1e9), flush=True)
-    ms = bench(lambda: ops.wgrad(A.data_ptr(), K, C.data_ptr(), N, N, B.data_ptr(), N, M, K, N, H.gemm_geom(), dev)) if False else None
+    Bt = torch.randn(K, N, device=dev)
+    ms = bench(lambda: ops.gemm(A.data_ptr(), K, Bt.data_ptr(), N, 1, C.data_ptr(), N, M, N, K, K, H.gemm_geom()))
+    print("bl1   M %7d N %5d K %5d : %8.3f ms  %6.1f TF/s" % (M, N, K, ms, 2.0 * M * N * K / ms / 1e9), flush=True)
 for (R, M, N) in [(25088, 256, 1024), (401408, 64, 256), (100352, 128, 512), (6272, 512, 2048)]:
     dY = torch.randn(R, M, device=dev); X = torch.randn(R, N, device=dev); dW = torch.empty(M, N, device=dev)
     ms = bench(lambda: ops.wgrad(dY.data_ptr(), M, X.data_ptr(), N, N, dW.data_ptr(), N, R, M, N, H.gemm_geom(), dev))
