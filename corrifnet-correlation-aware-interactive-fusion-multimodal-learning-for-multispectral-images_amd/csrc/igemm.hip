@@ -404,9 +404,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const uint32_t tiles_n = (p.N + BN - 1) / BN;
-    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    // 1-D grid over (row slab | batch) x tiles, remapped so that one XCD runs all the tiles of a slab: they re-read the same
+    // rows of A and B, which then come from that XCD's L2 instead of eight separate HBM / Infinity-Cache fetches.
+    const uint32_t tiles_mn = ((p.M + BM - 1) / BM) * tiles_n;
+    const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t zz = lin / tiles_mn, tile = lin - zz * tiles_mn;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     int split = 0, z = 0;
-    if (p.splits > 1) split = blockIdx.z; else z = blockIdx.z;
+    if (p.splits > 1) split = (int)zz; else z = (int)zz;
     const int zo = z / p.Zi, zi = z - zo * p.Zi;
     const float* __restrict__ A = p.A + zo * p.sA_o + zi * p.sA_i;
     const float* __restrict__ B = p.B + zo * p.sB_o + zi * p.sB_i;
@@ -615,12 +620,14 @@ extern "C" int corrif_wgrad(const CorrifWgrad* p, void* stream) {
     if (scalar) { BM = 64; BN = 128; }
     if (BN == 256) BM = 16;
     uint32_t tiles = (uint32_t)((p->M + BM - 1) / BM) * (uint32_t)((p->N + BN - 1) / BN);
-    dim3 grid(tiles, 1, p->splits > 1 ? p->splits : p->Z);
+    const uint32_t nz = (uint32_t)(p->splits > 1 ? p->splits : p->Z);
+    if ((uint64_t)tiles * nz >= (1ull << 31)) return CORRIF_EUNSUPPORTED;
+    dim3 grid(tiles * nz, 1, 1);
     if (scalar) {
-        grid.x = (uint32_t)((p->M + 63) / 64) * (uint32_t)((p->N + 127) / 128);
+        grid.x = (uint32_t)((p->M + 63) / 64) * (uint32_t)((p->N + 127) / 128) * nz;
         hipLaunchKernelGGL((wgrad_kernel<64, 128, 2, 2, 1, false>), grid, dim3(256), 0, s, a);
     } else if (BN == 256) {
-        int rc = launch_smallm_wgrad(a, (int)grid.z, s);
+        int rc = launch_smallm_wgrad(a, (int)nz, s);
         if (rc != CORRIF_OK) return rc;
     } else if (BM == 32) {
         if (a.g.is_gemm) hipLaunchKernelGGL((wgrad_kernel<32, 128, 1, 4, 4, true>), grid, dim3(256), 0, s, a);

@@ -12,6 +12,11 @@ x, mask = helpers.make_inputs(32, 4, 224, 224); x, mask = x.to(dev), mask.to(dev
 def step():
     model.zero_grad(set_to_none=True)
     loss = ops.bce_with_logits_mean(model(x), mask); loss.backward()
+if os.environ.get("MODE") == "gemm":       # back-to-back 4096^3 GEMMs instead of the model step
+    import corrif_hip as H
+    A = torch.randn(4096, 4096, device=dev); Bm = torch.randn(4096, 4096, device=dev); Cm = torch.empty(4096, 4096, device=dev)
+    def step():
+        for _ in range(150): ops.gemm(A.data_ptr(), 4096, Bm.data_ptr(), 4096, 1, Cm.data_ptr(), 4096, 4096, 4096, 4096, 4096, H.gemm_geom())
 for _ in range(2): step()
 torch.cuda.synchronize()
 N = 800
