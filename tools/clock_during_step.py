@@ -4,7 +4,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); import helpers  # noqa
 import torch, mmvit4, ops
 dev = "cuda:0"
-lib = ctypes.CDLL(os.path.join(ROOT, "tools", "probe", "clock_probe.so"))
+_so = os.path.join(ROOT, "tools", "probe", "clock_probe.so")
+if not os.path.exists(_so):       # hipcc --offload-arch=gfx950 -O3 -fPIC -shared tools/probe/clock_probe.hip -o tools/probe/clock_probe.so
+    import subprocess
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", _so[:-3] + ".hip", "-o", _so])
+lib = ctypes.CDLL(_so)
 lib.clock_probe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 torch.manual_seed(0)
 model = mmvit4.MMVit4().to(dev).train()
