@@ -36,43 +36,49 @@ struct PatchCfg {
     static constexpr int NKG = KCP / 64;
 };
 
-// NA accumulator quads: NG output-channel groups, doubled (even / odd k) when NG <= 2 so that consecutive MFMAs never wait
-// for the result of the one two slots earlier (the 4x4x1 MFMA issues in 2 passes but its result takes longer).
 template <int NG>
 struct PatchAcc { static constexpr int NA = NG; };
 
-template <int NG, int CC, int KG, int Bk>
-__device__ __forceinline__ void patch_mfma_step(f32x4 (&acc)[PatchAcc<NG>::NA], const f32x4 (&wreg)[NG], const float* __restrict__ patch, int pvoff,
-                                                int PH, int PW) {
-    constexpr int kidx = KG * 64 + Bk * 4;
-    if constexpr (kidx < 27 * CC) {
-        constexpr int tap = kidx / CC, c = kidx % CC;
-        constexpr int td = tap / 9, th = (tap / 3) % 3, tw = tap % 3;
-        const int off = (pvoff + (td * PH + th) * PW + tw) * (CC + 4) + c;
-        const f32x4 x4 = *reinterpret_cast<const f32x4*>(patch + off);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                constexpr int NA = PatchAcc<NG>::NA;
-                const int a = NA == NG ? g : (e & 1) * NG + g;
-                acc[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[g][e], x4[e], acc[a], 4, Bk, 0);
-            }
-    }
+// One step = 4 consecutive k (one float4 of this lane's voxel at a compile-time tap/channel offset) x NG output-channel groups.
+// The patch reads run TWO steps ahead of the MFMAs that consume them and the weight registers of the next 64-k group are
+// requested half a group early: a read -> wait -> 4 NG MFMAs chain exposes the LDS latency every 32 NG cycles.
+template <int CC, int T>
+__device__ __forceinline__ f32x4 patch_x4(const float* __restrict__ patch, int pvoff, int PH, int PW) {
+    constexpr int kidx = T * 4, tap = kidx / CC, c = kidx % CC;
+    constexpr int td = tap / 9, th = (tap / 3) % 3, tw = tap % 3;
+    return *reinterpret_cast<const f32x4*>(patch + (pvoff + (td * PH + th) * PW + tw) * (CC + 4) + c);
 }
-template <int NG, int CC, int KG, int... Bs>
-__device__ __forceinline__ void patch_kgroup(f32x4 (&acc)[PatchAcc<NG>::NA], const float* __restrict__ wl, const float* __restrict__ patch, int pvoff,
-                                             int PH, int PW, int lane, std::integer_sequence<int, Bs...>) {
+template <int NG, int CC, int KG>
+__device__ __forceinline__ void patch_wload(f32x4 (&wreg)[NG], const float* __restrict__ wl, int lane) {
     using Cfg = PatchCfg<NG, CC>;
-    f32x4 wreg[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) wreg[g] = *reinterpret_cast<const f32x4*>(wl + (g * 4 + (lane & 3)) * Cfg::WP + KG * 64 + (lane >> 2) * 4);
-    (patch_mfma_step<NG, CC, KG, Bs>(acc, wreg, patch, pvoff, PH, PW), ...);
 }
-template <int NG, int CC, int... KGs>
-__device__ __forceinline__ void patch_chunk(f32x4 (&acc)[PatchAcc<NG>::NA], const float* __restrict__ wl, const float* __restrict__ patch, int pvoff,
-                                            int PH, int PW, int lane, std::integer_sequence<int, KGs...>) {
-    (patch_kgroup<NG, CC, KGs>(acc, wl, patch, pvoff, PH, PW, lane, std::make_integer_sequence<int, 16>{}), ...);
+template <int NG, int CC, int T>
+__device__ __forceinline__ void patch_step(f32x4 (&acc)[NG], f32x4 (&wreg)[2][NG], f32x4 (&xb)[3], const float* __restrict__ wl,
+                                           const float* __restrict__ patch, int pvoff, int PH, int PW, int lane) {
+    constexpr int NSTEP = 27 * CC / 4, KG = T / 16, Bk = T % 16;
+    if constexpr (T + 2 < NSTEP) xb[(T + 2) % 3] = patch_x4<CC, T + 2>(patch, pvoff, PH, PW);
+    if constexpr (Bk == 8 && (KG + 1) * 16 < NSTEP) patch_wload<NG, CC, KG + 1>(wreg[(KG + 1) & 1], wl, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[KG & 1][g][e], xb[T % 3][e], acc[g], 4, Bk, 0);
+}
+template <int NG, int CC, int... Ts>
+__device__ __forceinline__ void patch_chunk_seq(f32x4 (&acc)[NG], const float* __restrict__ wl, const float* __restrict__ patch, int pvoff,
+                                                int PH, int PW, int lane, std::integer_sequence<int, Ts...>) {
+    f32x4 wreg[2][NG], xb[3];
+    patch_wload<NG, CC, 0>(wreg[0], wl, lane);
+    xb[0] = patch_x4<CC, 0>(patch, pvoff, PH, PW);
+    xb[1] = patch_x4<CC, 1>(patch, pvoff, PH, PW);
+    (patch_step<NG, CC, Ts>(acc, wreg, xb, wl, patch, pvoff, PH, PW, lane), ...);
+}
+template <int NG, int CC>
+__device__ __forceinline__ void patch_chunk(f32x4 (&acc)[NG], const float* __restrict__ wl, const float* __restrict__ patch, int pvoff,
+                                            int PH, int PW, int lane) {
+    patch_chunk_seq<NG, CC>(acc, wl, patch, pvoff, PH, PW, lane, std::make_integer_sequence<int, 27 * CC / 4>{});
 }
 
 // Persistent workgroups walk a contiguous range of tiles (neighbouring tiles share their halo through L2).  The work list
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256) void conv3_patch_kernel(PatchArgs p) {
         int ntile = tile, nch = ch + 1;
         if (nch == nchunk) { nch = 0; ++ntile; }
         if (it + 1 < nitems) issue(ntile, nch, !p.wres && nchunk > 1);      // in flight during the MFMAs below
-        patch_chunk<NG, CC>(acc, wl + (p.wres ? ch : 0) * 4 * NG * Cfg::WP, patch, pvoff, PH, PW, lane, std::make_integer_sequence<int, Cfg::NKG>{});
+        patch_chunk<NG, CC>(acc, wl + (p.wres ? ch : 0) * 4 * NG * Cfg::WP, patch, pvoff, PH, PW, lane);
         if (ch == nchunk - 1) {
             uint32_t t = (uint32_t)tile;
             const uint32_t b = fdiv(t, p.dT0);
@@ -257,7 +263,7 @@ static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 extern "C" int corrif_conv3_patch_cc(int32_t Ci, int32_t Co) {
     if (Co <= 0 || Co > 32 || (Co & 3) || Ci <= 0 || (Ci & 7)) return 0;
     if (Ci > 64) return 0;      // many channel chunks re-stage the halo too often: the implicit GEMM is faster there (d3_c2: 50 vs 38 TF/s)
-    return (Co <= 8 && !(Ci & 15)) ? 16 : 8;
+    return (Co <= 8 && !(Ci & 15)) ? 16 : 8;     // measured: 8-channel chunks (more co-resident workgroups) are not faster for Cout <= 8
 }
 
 extern "C" int corrif_conv3_patch(const CorrifConv3Patch* q, void* stream) {
@@ -319,17 +325,18 @@ struct PatchWgArgs {
     FastDiv dHW, dW, dT0, dT1, dT2;
 };
 
-template <int NG, int VB>
-__device__ __forceinline__ void wg_step(f32x4 (&a)[NG], const float (&areg)[NG], const float* __restrict__ xaddr) {
-    // xaddr already includes the lane's column offset and the w-row base; VB*16 floats = this voxel inside the w-row
-    const float x = xaddr[VB * 16];
+// half a w-row (8 voxels, ABID = HB*8 .. HB*8+7) of one column group
+template <int NG, int HB, int... Vs>
+__device__ __forceinline__ void wg_half(f32x4 (&a)[NG], const float (&areg)[NG], const float (&x)[8], std::integer_sequence<int, Vs...>) {
+    ([&] {
 #pragma unroll
-    for (int g = 0; g < NG; ++g) a[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(areg[g], x, a[g], 4, VB, 0);
+        for (int g = 0; g < NG; ++g) a[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(areg[g], x[Vs], a[g], 4, HB * 8 + Vs, 0);
+    }(), ...);
 }
-template <int NG, int... VBs>
-__device__ __forceinline__ void wg_cgroup(f32x4 (&a)[NG], const float (&areg)[NG], const float* __restrict__ xaddr,
-                                          std::integer_sequence<int, VBs...>) {
-    (wg_step<NG, VBs>(a, areg, xaddr), ...);
+// 8 voxels of one w-row for this lane's column: xaddr includes the column offset, the w-row base and the half; voxel v sits 16 floats on
+__device__ __forceinline__ void wg_load8(float (&x)[8], const float* __restrict__ xaddr) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) x[v] = xaddr[v * 16];
 }
 
 template <int NG, int NCH, int NPF>
@@ -445,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_wgrad_kernel(PatchWgArgs p
 
     // NG >= 3: the accumulators (28 NG registers) leave no room to hold the next item across the MFMA section without spilling,
     // so those variants load right before the LDS stores (two workgroups per CU still overlap each other's staging).
-    constexpr bool PF = NG <= 2;
+    constexpr bool PF = NG <= 2 && NPF <= 11;     // (the shallow-grid NPF = 16 variants would spill as well)
     int tile = blockIdx.x;
     if (PF && tile < p.ntiles) { issue_patch(tile, 0); issue_dy(tile); }
     for (; tile < p.ntiles; tile += gridDim.x) {
@@ -478,17 +485,37 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_wgrad_kernel(PatchWgArgs p
                     issue_dy(tile + (int)gridDim.x);
                 }
             }
-            // ---- this wave's 64 voxels = 4 w-rows of 16
+            // ---- this wave's 64 voxels = 4 w-rows of 16.  The X values of column group cg+1 (and of the next w-row's first
+            //      group) are requested before the 16 NG MFMAs of group cg issue: a ds_read -> wait -> 4 MFMAs chain exposed the
+            //      LDS latency every 32 cycles.
+            auto rowoff_of = [&](int r) { return (((r >> p.lth) * PH + (r & (TH - 1))) * PW) * CP; };
+            float xb[2][8];
+            float areg[2][NG];
+            wg_load8(xb[0], patch + rowoff_of(wave * 4) + colbase[0]);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) areg[0][g] = dys[(wave * 4 * 16 + (lane >> 2)) * DP + g * 4 + (lane & 3)];
+#pragma unroll
             for (int vq = 0; vq < 4; ++vq) {
                 const int r = wave * 4 + vq;                    // w-row inside the tile
-                const int vd = r >> p.lth, vh = r & (TH - 1);
-                const int rowoff = ((vd * PH + vh) * PW) * CP;
-                float areg[NG];
+                int ro = rowoff_of(r), ro_next = rowoff_of(r + 1);           // r + 1 of the last row stays inside the halo'd patch (unused)
+                // opaque to the optimiser: otherwise all 28 (row, column group) LDS addresses are hoisted out of the persistent tile
+                // loop and held in registers for the whole kernel (spills); one v_add per 8 reads is free
+                asm volatile("" : "+v"(ro), "+v"(ro_next));
+                if (vq + 1 < 4) {
 #pragma unroll
-                for (int g = 0; g < NG; ++g) areg[g] = dys[(r * 16 + (lane >> 2)) * DP + g * 4 + (lane & 3)];
+                    for (int g = 0; g < NG; ++g) areg[(vq + 1) & 1][g] = dys[((r + 1) * 16 + (lane >> 2)) * DP + g * 4 + (lane & 3)];
+                }
 #pragma unroll
-                for (int cg = 0; cg < 7; ++cg)
-                    wg_cgroup<NG>(acc[ch][cg], areg, patch + rowoff + colbase[cg], std::make_integer_sequence<int, 16>{});
+                for (int cg = 0; cg < 7; ++cg) {
+                    // first half: voxels 0..7 are in xb[0]; request voxels 8..15, then the next group's (or next row's) first half
+                    wg_load8(xb[1], patch + ro + colbase[cg] + 8 * 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                    wg_half<NG, 0>(acc[ch][cg], areg[vq & 1], xb[0], std::make_integer_sequence<int, 8>{});
+                    if (cg + 1 < 7) wg_load8(xb[0], patch + ro + colbase[cg + 1]);
+                    else if (vq + 1 < 4) wg_load8(xb[0], patch + ro_next + colbase[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    wg_half<NG, 1>(acc[ch][cg], areg[vq & 1], xb[1], std::make_integer_sequence<int, 8>{});
+                }
             }
         }
     }
@@ -581,10 +608,7 @@ extern "C" int corrif_conv3_patch_wgrad(const CorrifConv3PatchWgrad* q, void* st
     dim3 grid(wgs, 1, nz);          // slabs of workgroups that own no tile stay zero: the kernel still writes them
     int rc = CORRIF_EUNSUPPORTED;
     const int npv = (TD + 2) * PH * 18;
-    if (NG == 1 && NCH == 4) rc = launch_wg<1, 4>(a, grid, lds, npv, s);
-    else if (NG == 1 && NCH == 2) rc = launch_wg<1, 2>(a, grid, lds, npv, s);
-    else if (NG == 1 && NCH == 1) rc = launch_wg<1, 1>(a, grid, lds, npv, s);
-    else if (NG == 2 && NCH == 2) rc = launch_wg<2, 2>(a, grid, lds, npv, s);
+    if (NG == 1 && NCH == 1) rc = launch_wg<1, 1>(a, grid, lds, npv, s);
     else if (NG == 2 && NCH == 1) rc = launch_wg<2, 1>(a, grid, lds, npv, s);
     else if (NG == 3) rc = launch_wg<3, 1>(a, grid, lds, npv, s);
     else if (NG == 4) rc = launch_wg<4, 1>(a, grid, lds, npv, s);

@@ -505,18 +505,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
             store_tile();
             __syncthreads();
             if (r0 + 32 < r_end) load_tile(r0 + 32);
+            // fragments of k-pair s+2 are requested before the MFMAs of pair s are issued (two pairs of LDS latency cover)
+            float a[3][TM], b[3][TN];
+            auto frag = [&](int s, float (&fa)[TM], float (&fb)[TN]) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = As[(2 * s + fh) * PA + (wm * TM + i) * 32 + fi];
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) fb[jj] = Bs[(2 * s + fh) * PB + (wn * TN + jj) * 32 + fi];
+            };
+            frag(0, a[0], b[0]);
+            frag(1, a[1], b[1]);
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                float a[TM], b[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = As[(2 * s + fh) * PA + (wm * TM + i) * 32 + fi];
-#pragma unroll
-                for (int jj = 0; jj < TN; ++jj) b[jj] = Bs[(2 * s + fh) * PB + (wn * TN + jj) * 32 + fi];
+                if (s + 2 < 16) frag(s + 2, a[(s + 2) % 3], b[(s + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);          // keep the reads ahead: the scheduler otherwise sinks them next to their use
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int jj = 0; jj < TN; ++jj)
-                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jj], acc[i][jj], 0, 0, 0);
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s % 3][i], b[s % 3][jj], acc[i][jj], 0, 0, 0);
             }
             __syncthreads();
         }
