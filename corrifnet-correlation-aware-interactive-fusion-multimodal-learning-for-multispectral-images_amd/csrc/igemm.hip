@@ -40,24 +40,23 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
 
     // ---- per-thread staging roles: A chunk column kc (fixed), rows ar + 32*i
     const int kc = tid & 7, ar = tid >> 3;
-    int64_t a_base[AI];
-    uint32_t a_pack[AI];
+    // per row: GEMM mode needs nothing but the row number; gather mode keeps the sample index and the packed (d,h,w) of the row
+    // (32-bit each: the 64-bit base is re-derived at the load, registers are what limits the workgroups per CU)
+    uint32_t a_n[AI], a_pack[AI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
         int row = m0 + ar + 32 * i;
+        a_n[i] = 0;
+        a_pack[i] = 0xFFFFFFFFu;
         if (row < p.M) {
             if constexpr (GEMM) {
-                a_base[i] = (int64_t)row * p.lda;
                 a_pack[i] = 0;
             } else {
                 uint32_t n, pk;
                 decode_row((uint32_t)row, p.g, n, pk);
-                a_base[i] = (int64_t)n * p.g.sample_pitch;
+                a_n[i] = n;
                 a_pack[i] = pk;
             }
-        } else {
-            a_base[i] = 0;
-            a_pack[i] = 0xFFFFFFFFu;
         }
     }
 
@@ -110,7 +109,7 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
                 const bool ok = kin && (GEMM ? a_pack[i] != 0xFFFFFFFFu : a_off[i] >= 0);
-                const int64_t off = GEMM ? a_base[i] + k : a_base[i] + a_off[i] + c;
+                const int64_t off = GEMM ? (int64_t)(m0 + ar + 32 * i) * p.lda + k : (int64_t)a_n[i] * p.g.sample_pitch + a_off[i] + c;
                 ra[i] = *reinterpret_cast<const f32x4*>(A + (ok ? off : 0));
                 okA |= (uint32_t)ok << i;
             }
@@ -134,7 +133,7 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
                 for (int e = 0; e < 4; ++e) {
                     int vox;
                     const bool ok = kin && a_pack[i] != 0xFFFFFFFFu && tok[e] && gather_voxel(a_pack[i], td[e], th[e], tw[e], p.g, vox);
-                    const float x = A[ok ? a_base[i] + (int64_t)vox * p.lda : 0];      // unconditional load, select afterwards
+                    const float x = A[ok ? (int64_t)a_n[i] * p.g.sample_pitch + (int64_t)vox * p.lda : 0];      // unconditional load, select afterwards
                     v[e] = ok ? x : 0.f;
                 }
                 ra[i] = v;

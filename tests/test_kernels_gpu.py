@@ -57,6 +57,10 @@ CONVS = [
     ("3x3x3_zero_d1", 16, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, (2, 1, 9, 20), True),
     ("3x3x3_rep_d2", 8, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (2, 2, 17, 33), False),
     ("3x3x3_zero_48", 48, 48, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, (1, 4, 10, 10), True),
+    # > 512 tiles: persistent patch workgroups walk several tiles each (resident weights / per-chunk weights / single chunk)
+    ("3x3x3_rep_32_8_many_tiles", 32, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (2, 20, 64, 64), True),
+    ("3x3x3_zero_64_16_many_tiles", 64, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, (2, 18, 64, 60), True),
+    ("3x3x3_rep_8_32_many_tiles", 8, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (2, 20, 64, 64), False),
     ("1x1_12_to_4", 12, 4, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 5, 6, 7), True),
     ("1x1_16_16", 16, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 7, 9, 11), True),
     ("1x1_n8", 8, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 6, 6, 6), True),
