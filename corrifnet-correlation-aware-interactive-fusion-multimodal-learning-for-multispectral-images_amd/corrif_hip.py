@@ -45,7 +45,7 @@ class Wgrad(C.Structure):
 class Conv3Patch(C.Structure):
     _fields_ = [("X", ptr), ("ldx", i64), ("Wp", ptr), ("Y", ptr), ("ldy", i64), ("bias", ptr),
                 ("B", i32), ("Sd", i32), ("Sh", i32), ("Sw", i32), ("Od", i32), ("Oh", i32), ("Ow", i32),
-                ("Ci", i32), ("Co", i32), ("pad", i32), ("clamp", i32), ("cc", i32)]
+                ("Ci", i32), ("Co", i32), ("pad", i32), ("clamp", i32), ("cc", i32), ("fold", i32)]
 
 
 class Conv3PatchWgrad(C.Structure):

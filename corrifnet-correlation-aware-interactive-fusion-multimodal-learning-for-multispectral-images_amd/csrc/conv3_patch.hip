@@ -21,7 +21,7 @@ struct PatchArgs {
     const float* Wp;                 // [nchunk][Co][27*CC]
     float* Y; int64_t ldy;
     const float* bias;
-    int B, Sd, Sh, Sw, Od, Oh, Ow, Ci, Co, pad, clamp, ntiles, wres;
+    int B, Sd, Sh, Sw, Od, Oh, Ow, Ci, Co, pad, clamp, ntiles, wres, fold, patch_floats;
     int ltd, lth, ltw, ntd, nth, ntw;
     FastDiv dHW, dW;                 // patch voxel index -> (pd, ph, pw)
     FastDiv dT0, dT1, dT2;           // tile index -> (b, td, th, tw)
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void conv3_patch_kernel(PatchArgs p) {
     const int NPV = PD * PH * PW;
     float* wl = smem;                                   // [4*NG][WP]
     float* patch = smem + (p.wres ? p.Ci / CC : 1) * 4 * NG * Cfg::WP;      // [NPV][CP]
-    float* biasl = patch + NPV * Cfg::CP;               // [4*NG]
+    float* biasl = patch + p.patch_floats;              // [4*NG]; patch_floats = max(NPV * CP, fold staging 256 * (4 NG + 4))
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 4 * NG) biasl[tid] = (p.bias && tid < p.Co) ? p.bias[tid] : 0.f;
@@ -207,15 +207,44 @@ __global__ __launch_bounds__(256) void conv3_patch_kernel(PatchArgs p) {
             const uint32_t ith = fdiv(t, p.dT2);
             const uint32_t itw = t - ith * p.dT2.d;
             const int od = (int)(itd << p.ltd) + vd, oh = (int)(ith << p.lth) + vh, ow = (int)(itw << p.ltw) + vw;
-            if (od < p.Od && oh < p.Oh && ow < p.Ow) {
-                const int64_t row = (((int64_t)b * p.Od + od) * p.Oh + oh) * p.Ow + ow;
+            if (!p.fold) {
+                if (od < p.Od && oh < p.Oh && ow < p.Ow) {
+                    const int64_t row = (((int64_t)b * p.Od + od) * p.Oh + oh) * p.Ow + ow;
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    if (g * 4 >= p.Co) continue;
-                    f32x4 v = acc[g];
-                    if constexpr (NA != NG) v += acc[NG + g];
-                    v += *reinterpret_cast<const f32x4*>(biasl + g * 4);       // LDS copy: a global load here would wait for the prefetch in flight
-                    *reinterpret_cast<f32x4*>(p.Y + row * p.ldy + g * 4) = v;
+                    for (int g = 0; g < NG; ++g) {
+                        if (g * 4 >= p.Co) continue;
+                        f32x4 v = acc[g];
+                        v += *reinterpret_cast<const f32x4*>(biasl + g * 4);       // LDS copy: a global load here would wait for the prefetch in flight
+                        *reinterpret_cast<f32x4*>(p.Y + row * p.ldy + g * 4) = v;
+                    }
+                }
+            } else {
+                // Adjoint of replicate padding folded into the epilogue: this tile lives on the (n+2)^3 padded grid; padded
+                // coordinate 0 belongs to voxel 1 and n+1 to voxel n.  n is a multiple of the tile extent on every axis (host
+                // check), so both members of a pair sit in the SAME tile: the tile's results go through LDS once and every real
+                // voxel sums its up to 2x2x2 pre-images in a fixed order (deterministic, no (n+2)^3 buffer, no pad_fold pass).
+                constexpr int RP = 4 * NG + 4;
+                float* res = patch;                                  // the patch is dead until the next item's staging
+                __syncthreads();
+#pragma unroll
+                for (int g = 0; g < NG; ++g) *reinterpret_cast<f32x4*>(res + lv * RP + g * 4) = acc[g];
+                __syncthreads();
+                const int nd = p.Od - 2, nh = p.Oh - 2, nw = p.Ow - 2;
+                if (od >= 1 && od <= nd && oh >= 1 && oh <= nh && ow >= 1 && ow <= nw) {
+                    const int d_lo = od == 1 ? -1 : 0, d_hi = od == nd ? 1 : 0;
+                    const int h_lo = oh == 1 ? -1 : 0, h_hi = oh == nh ? 1 : 0;
+                    const int w_lo = ow == 1 ? -1 : 0, w_hi = ow == nw ? 1 : 0;
+                    const int64_t row = (((int64_t)b * nd + (od - 1)) * nh + (oh - 1)) * nw + (ow - 1);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        if (g * 4 >= p.Co) continue;
+                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                        for (int dd = d_lo; dd <= d_hi; ++dd)
+                            for (int hh = h_lo; hh <= h_hi; ++hh)
+                                for (int ww = w_lo; ww <= w_hi; ++ww)
+                                    v += *reinterpret_cast<const f32x4*>(res + (lv + ((dd << p.lth) + hh) * TW + ww) * RP + g * 4);
+                        *reinterpret_cast<f32x4*>(p.Y + row * p.ldy + g * 4) = v;
+                    }
                 }
             }
 #pragma unroll
@@ -248,7 +277,9 @@ static int launch_patch(const PatchArgs& a, unsigned tiles, int npv, hipStream_t
     using Cfg = PatchCfg<NG, CC>;
     PatchArgs b = a;
     const int nchunk = a.Ci / CC;
-    const size_t fixed = (size_t)(npv * Cfg::CP + 4 * NG) * sizeof(float), wchunk = (size_t)4 * NG * Cfg::WP * sizeof(float);
+    b.patch_floats = npv * Cfg::CP;
+    if (a.fold && b.patch_floats < 256 * (4 * NG + 4)) b.patch_floats = 256 * (4 * NG + 4);
+    const size_t fixed = (size_t)(b.patch_floats + 4 * NG) * sizeof(float), wchunk = (size_t)4 * NG * Cfg::WP * sizeof(float);
     b.wres = nchunk > 1 && fixed + nchunk * wchunk <= 80 * 1024;         // all weight chunks resident while two workgroups still share a CU
     const size_t lds = fixed + (b.wres ? nchunk : 1) * wchunk;
     if (lds > 160 * 1024) return CORRIF_EUNSUPPORTED;
@@ -278,7 +309,10 @@ extern "C" int corrif_conv3_patch(const CorrifConv3Patch* q, void* stream) {
     PatchArgs a;
     a.X = q->X; a.ldx = q->ldx; a.Wp = q->Wp; a.Y = q->Y; a.ldy = q->ldy; a.bias = q->bias;
     a.B = q->B; a.Sd = q->Sd; a.Sh = q->Sh; a.Sw = q->Sw; a.Od = q->Od; a.Oh = q->Oh; a.Ow = q->Ow;
-    a.Ci = q->Ci; a.Co = q->Co; a.pad = q->pad; a.clamp = q->clamp;
+    a.Ci = q->Ci; a.Co = q->Co; a.pad = q->pad; a.clamp = q->clamp; a.fold = q->fold;
+    if (q->fold) {      // O = (n+2)^3 padded grid, Y = the n^3 gradient; pairs (0,1) / (n,n+1) must share a 4 x 4 x 16 tile
+        if (q->pad != 2 || q->clamp || q->bias || q->Od < 6 || ((q->Od - 2) & 3) || ((q->Oh - 2) & 3) || ((q->Ow - 2) & 15)) return CORRIF_EUNSUPPORTED;
+    }
     // 256-voxel tile: prefer 4 x 4 x 16; squeeze the depth for shallow grids
     int TD = 4, TH = 4, TW = 16;
     if (q->Od < 4) { TD = q->Od >= 2 ? 2 : 1; TH = 256 / (TD * TW); }

@@ -113,8 +113,9 @@ def repack(src, shape_out, O, I, T, mode, ldo, zero=False):
     return out
 
 
-def conv3_patch(x, ldx, wp, y, ldy, bias, B, S, O, Ci, Co, pad, clamp, cc):
+def conv3_patch(x, ldx, wp, y, ldy, bias, B, S, O, Ci, Co, pad, clamp, cc, fold=False):
     q = H.Conv3Patch()
+    q.fold = 1 if fold else 0
     q.X, q.ldx, q.Wp, q.Y, q.ldy = x, ldx, wp, y, ldy
     q.bias = bias
     q.B = B
@@ -264,9 +265,12 @@ class ConvFn(Function):
                 wd = repack(weight, (Co // cc, Ci, T, cc), Co, Ci, T, 4, cc)
                 if replicate:
                     Rg = (Di + 2, Hi + 2, Wi + 2)
-                    gxp = torch.empty((B,) + Rg + (Ci,), dtype=torch.float32, device=dev)
-                    conv3_patch(P(gy), ldg, P(wd), P(gxp), Ci, 0, B, (Do, Ho, Wo), Rg, Co, Ci, 2, False, cc)
-                    check(lib().corrif_pad_fold(P(gxp), P(gx), Ci, B, Di, Hi, Wi, Ci, stream()), "corrif_pad_fold")
+                    if Di % 4 == 0 and Hi % 4 == 0 and Wi % 16 == 0:      # padding adjoint fused into the kernel's epilogue
+                        conv3_patch(P(gy), ldg, P(wd), P(gx), Ci, 0, B, (Do, Ho, Wo), Rg, Co, Ci, 2, False, cc, fold=True)
+                    else:
+                        gxp = torch.empty((B,) + Rg + (Ci,), dtype=torch.float32, device=dev)
+                        conv3_patch(P(gy), ldg, P(wd), P(gxp), Ci, 0, B, (Do, Ho, Wo), Rg, Co, Ci, 2, False, cc)
+                        check(lib().corrif_pad_fold(P(gxp), P(gx), Ci, B, Di, Hi, Wi, Ci, stream()), "corrif_pad_fold")
                 else:
                     conv3_patch(P(gy), ldg, P(wd), P(gx), Ci, 0, B, (Do, Ho, Wo), (Di, Hi, Wi), Co, Ci, 1, False, cc)
             else:

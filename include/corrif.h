@@ -138,7 +138,7 @@ int corrif_weight_repack(const float* in, float* out, int32_t O, int32_t I, int3
  * broadcast.  out[o] = bias + sum_t W[t] . X[clamp|zero(o + t - pad)],  o in the Od x Oh x Ow grid.
  *   forward      : pad = 1, (Od,Oh,Ow) = (Sd,Sh,Sw), clamp = replicate?   weights from corrif_weight_repack mode 3
  *   data gradient: X = dY, weights mode 4 (flipped taps, transposed channels); zero padding: pad = 1 same grid;
- *                  replicate padding: pad = 2 on the (S+2)^3 grid, then corrif_pad_fold.
+ *                  replicate padding: pad = 2 on the (S+2)^3 grid, then corrif_pad_fold (or fold = 1: fused).
  * cc must equal corrif_conv3_patch_cc(Ci, Co) (channel chunk, 16 or 8; 0 = shape not supported). */
 typedef struct CorrifConv3Patch {
     const float* X; int64_t ldx;
@@ -146,6 +146,8 @@ typedef struct CorrifConv3Patch {
     float* Y; int64_t ldy;
     const float* bias;               /* [Co] or NULL */
     int32_t B, Sd, Sh, Sw, Od, Oh, Ow, Ci, Co, pad, clamp, cc;
+    int32_t fold;                    /* 1: data gradient of a replicate-padded conv with the padding adjoint fused: O = (n+2)^3 padded grid,
+                                      * pad = 2, Y = the n^3 input gradient (rows of the n grid); needs n_d % 4 == n_h % 4 == n_w % 16 == 0 */
 } CorrifConv3Patch;
 int corrif_conv3_patch(const CorrifConv3Patch* p, void* stream);
 int corrif_conv3_patch_cc(int32_t Ci, int32_t Co);     /* host-only */

@@ -61,6 +61,9 @@ CONVS = [
     ("3x3x3_rep_32_8_many_tiles", 32, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (2, 20, 64, 64), True),
     ("3x3x3_zero_64_16_many_tiles", 64, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, (2, 18, 64, 60), True),
     ("3x3x3_rep_8_32_many_tiles", 8, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (2, 20, 64, 64), False),
+    # replicate padding with n % (4, 4, 16) == 0: the data gradient folds the padding adjoint in its epilogue (every tile touches a border)
+    ("3x3x3_rep_16_8_fold", 16, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (2, 4, 8, 16), True),
+    ("3x3x3_rep_8_24_fold", 8, 24, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (1, 8, 4, 32), False),
     ("1x1_12_to_4", 12, 4, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 5, 6, 7), True),
     ("1x1_16_16", 16, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 7, 9, 11), True),
     ("1x1_n8", 8, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 6, 6, 6), True),
