@@ -459,24 +459,34 @@ class MMVit4(nn.Module):
         mm = [ops.add(skip[i], corr[i]) for i in range(num_modals)]
         mm.append(self.fused6_encode_conv(fused[5]).view(B, P3 ** 3, T))
         pos = ops.cat_tokens(self.RGB_pos, self.NIR_pos, self.SWIR_pos, self.fused6_pos)
-        y = self.multimodal_transformer(ops.cat_tokens(*mm), pos)                          # [B, 2048, 512]
-        x6 = self.multimodal_decode_conv(y.view(B, P3, P3, P3, 4 * T))                     # 4 tokens -> one voxel (mmvit4.py:526)
+        tokens = ops.cat_tokens(*mm)                                                       # [B, 2048, 512]
+
+        def tail(tok, f1, f2, f3, f4, lane=0):
+            nb = tok.shape[0]
+            y = self.multimodal_transformer(tok, pos)
+            x6 = self.multimodal_decode_conv(y.view(nb, P3, P3, P3, 4 * T))                # 4 tokens -> one voxel (mmvit4.py:526)
+            return self.decoder_fuse(f1, f2, f3, f4, x6, lane=lane)
+
         lanes = min(int(self.decoder_split), B) if self.decoder_split else 1
         if lanes < 2:
-            return self.decoder_fuse(fused[0], fused[1], fused[2], fused[3], x6)
+            return tail(tokens, fused[0], fused[1], fused[2], fused[3])
+        # Everything after the inter-modal correlation is per sample: the multimodal transformer and the decoder run as `lanes`
+        # sample-group chains on separate streams, so one chain's softmax / LayerNorm / InstanceNorm / resampling passes overlap the
+        # other's matrix work (the transformer alone is a single chain with ~10 ms of exposed HBM-bound passes per step).
         cur = torch.cuda.current_stream()
         if self._dec_streams is None or len(self._dec_streams) < lanes:
             self._dec_streams = [torch.cuda.Stream(device=x.device) for _ in range(lanes)]
         bounds = [B * k // lanes for k in range(lanes + 1)]
-        ins = [ops.split_batch(t, bounds) for t in (fused[0], fused[1], fused[2], fused[3], x6)]
+        ins = [ops.split_batch(t, bounds) for t in (tokens, fused[0], fused[1], fused[2], fused[3])]
         outs = []
         for k in range(lanes):
             st = self._dec_streams[k]
             st.wait_stream(cur)
+            pos.record_stream(st)
             for t in ins:
                 t[k].record_stream(st)
             with torch.cuda.stream(st):
-                outs.append(self.decoder_fuse(*[t[k] for t in ins], lane=k))
+                outs.append(tail(*[t[k] for t in ins], lane=k))
         for k in range(lanes):
             cur.wait_stream(self._dec_streams[k])
             outs[k].record_stream(cur)
