@@ -38,3 +38,26 @@ for b in range(NB):
         if o > 0: c[n.split("(")[0][:40]] += o
     top = ", ".join("%s %.1f" % (k.replace("void ", ""), v / 1e6) for k, v in c.most_common(4))
     print("[%5.0f-%5.0f ms] busy-sum %.1f : %s" % ((lo - t0) / 1e6, (hi - t0) / 1e6, sum(c.values()) / 1e6, top))
+
+# ---- which kernels run while NO MFMA kernel is resident (the exposed non-MFMA time), and when
+iv = sorted((max(s, t0), e) for s, e, n, q in ev if is_mfma(n))
+merged = []
+for s, e in iv:
+    if merged and s <= merged[-1][1]: merged[-1][1] = max(merged[-1][1], e)
+    else: merged.append([s, e])
+gaps = []
+prev = t0
+for s, e in merged:
+    if s > prev: gaps.append((prev, s))
+    prev = max(prev, e)
+if prev < t_end: gaps.append((prev, t_end))
+c = collections.Counter()
+for s, e, n, q in ev:
+    if is_mfma(n): continue
+    for gs, ge in gaps:
+        o = min(e, ge) - max(s, gs)
+        if o > 0: c[n.split("(")[0][:48].replace("void ", "")] += o
+print("exposed (no MFMA kernel resident): %.1f ms in %d gaps; kernels running then (busy ms):" % (sum(g[1] - g[0] for g in gaps) / 1e6, len(gaps)))
+for k, v in c.most_common(14): print("   %-50s %.2f" % (k, v / 1e6))
+big = sorted(gaps, key=lambda g: g[0] - g[1])[:12]
+print("largest gaps (start ms, length ms):", [(round((g[0] - t0) / 1e6, 1), round((g[1] - g[0]) / 1e6, 2)) for g in sorted(big)])
