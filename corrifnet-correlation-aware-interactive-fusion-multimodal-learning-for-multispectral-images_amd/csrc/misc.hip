@@ -640,6 +640,7 @@ extern "C" int corrif_softmax_rows(float* s, int64_t rows, int32_t n, float scal
     if (n == 256) hipLaunchKernelGGL((softmax_rows_kernel<1>), grid, dim3(256), 0, st, s, rows, scale);
     else if (n == 512) hipLaunchKernelGGL((softmax_rows_kernel<2>), grid, dim3(256), 0, st, s, rows, scale);
     else if (n == 1024) hipLaunchKernelGGL((softmax_rows_kernel<4>), grid, dim3(256), 0, st, s, rows, scale);
+    else if (n == 1536) hipLaunchKernelGGL((softmax_rows_kernel<6>), grid, dim3(256), 0, st, s, rows, scale);      // MMVit2's 3 x 512 multimodal tokens
     else if (n == 2048) hipLaunchKernelGGL((softmax_rows_kernel<8>), grid, dim3(256), 0, st, s, rows, scale);
     else return CORRIF_EUNSUPPORTED;
     CORRIF_CHECK_LAUNCH();
@@ -654,6 +655,7 @@ extern "C" int corrif_softmax_dropout_rows(float* s, float* pd, int64_t rows, in
     const float ik = 1.0f / (1.0f - p);
     if (n == 512) hipLaunchKernelGGL((softmax_dropout_rows_kernel<2>), grid, dim3(256), 0, st, s, pd, rows, scale, p, ik, seed, offset / 4);
     else if (n == 1024) hipLaunchKernelGGL((softmax_dropout_rows_kernel<4>), grid, dim3(256), 0, st, s, pd, rows, scale, p, ik, seed, offset / 4);
+    else if (n == 1536) hipLaunchKernelGGL((softmax_dropout_rows_kernel<6>), grid, dim3(256), 0, st, s, pd, rows, scale, p, ik, seed, offset / 4);      // MMVit2's 3 x 512 multimodal tokens
     else if (n == 2048) hipLaunchKernelGGL((softmax_dropout_rows_kernel<8>), grid, dim3(256), 0, st, s, pd, rows, scale, p, ik, seed, offset / 4);
     else return CORRIF_EUNSUPPORTED;
     CORRIF_CHECK_LAUNCH();
@@ -668,6 +670,7 @@ extern "C" int corrif_softmax_dropout_rows_bwd(const float* pr, float* dpd_to_ds
     const float ik = 1.0f / (1.0f - p);
     if (n == 512) hipLaunchKernelGGL((softmax_dropout_rows_bwd_kernel<2>), grid, dim3(256), 0, st, pr, dpd_to_ds, rows, scale, p, ik, seed, offset / 4);
     else if (n == 1024) hipLaunchKernelGGL((softmax_dropout_rows_bwd_kernel<4>), grid, dim3(256), 0, st, pr, dpd_to_ds, rows, scale, p, ik, seed, offset / 4);
+    else if (n == 1536) hipLaunchKernelGGL((softmax_dropout_rows_bwd_kernel<6>), grid, dim3(256), 0, st, pr, dpd_to_ds, rows, scale, p, ik, seed, offset / 4);      // MMVit2's 3 x 512 multimodal tokens
     else if (n == 2048) hipLaunchKernelGGL((softmax_dropout_rows_bwd_kernel<8>), grid, dim3(256), 0, st, pr, dpd_to_ds, rows, scale, p, ik, seed, offset / 4);
     else return CORRIF_EUNSUPPORTED;
     CORRIF_CHECK_LAUNCH();
@@ -681,6 +684,7 @@ extern "C" int corrif_softmax_rows_bwd(const float* p, float* dp_to_ds, int64_t 
     if (n == 256) hipLaunchKernelGGL((softmax_rows_bwd_kernel<1>), grid, dim3(256), 0, st, p, dp_to_ds, rows, scale);
     else if (n == 512) hipLaunchKernelGGL((softmax_rows_bwd_kernel<2>), grid, dim3(256), 0, st, p, dp_to_ds, rows, scale);
     else if (n == 1024) hipLaunchKernelGGL((softmax_rows_bwd_kernel<4>), grid, dim3(256), 0, st, p, dp_to_ds, rows, scale);
+    else if (n == 1536) hipLaunchKernelGGL((softmax_rows_bwd_kernel<6>), grid, dim3(256), 0, st, p, dp_to_ds, rows, scale);      // MMVit2's 3 x 512 multimodal tokens
     else if (n == 2048) hipLaunchKernelGGL((softmax_rows_bwd_kernel<8>), grid, dim3(256), 0, st, p, dp_to_ds, rows, scale);
     else return CORRIF_EUNSUPPORTED;
     CORRIF_CHECK_LAUNCH();

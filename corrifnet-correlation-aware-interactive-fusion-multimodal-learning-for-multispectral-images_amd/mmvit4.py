@@ -204,10 +204,11 @@ class Encoder(nn.Module):
 class Decoder_fuse(nn.Module):
     """mmvit4.py:222-292 (seg_* heads are parameter-bearing but unused, as in the reference)."""
 
-    def __init__(self, num_cls=1):
+    def __init__(self, num_cls=1, reduce5=True):
+        """reduce5=False builds the sibling model's decoder (mmmvit2.py:116-219): no RFM5_reduce, d4_c1 is 192 -> 128"""
         super().__init__()
         b, rep = basic_dims, "replicate"
-        self.d4_c1 = general_conv3d_prenorm(b * 16, b * 16, pad_type=rep)
+        self.d4_c1 = general_conv3d_prenorm(b * 16 if reduce5 else b * 24, b * 16, pad_type=rep)
         self.d4_c2 = general_conv3d_prenorm(320, b * 8, pad_type=rep)
         self.d4_out = general_conv3d_prenorm(b * 8, b * 8, k_size=1, padding=0, pad_type=rep)
         self.d3_c1 = general_conv3d_prenorm(b * 8, b * 4, pad_type=rep)
@@ -225,7 +226,10 @@ class Decoder_fuse(nn.Module):
         self.seg_d1 = Conv3dP(b * 2, num_cls, 1)
         self.seg_layer = Conv3dP(b, num_cls, 1)
         self.RFM5 = fusion_prenorm(b * 24)
-        self.RFM5_reduce = Conv3dP(b * 24, b * 16, 1)
+        if reduce5:
+            self.RFM5_reduce = Conv3dP(b * 24, b * 16, 1)
+        else:
+            self.RFM5_reduce = None
         self.RFM4 = fusion_prenorm(b * 24)
         self.RFM3 = fusion_prenorm(b * 12)
         self.RFM2 = fusion_prenorm(b * 6)
@@ -264,7 +268,9 @@ class Decoder_fuse(nn.Module):
                     ev = torch.cuda.Event()
                     ev.record(side)
                     events.append(ev)
-        y = self.RFM5_reduce(self.RFM5(x5))
+        y = self.RFM5(x5)
+        if self.RFM5_reduce is not None:
+            y = self.RFM5_reduce(y)
         for l, (rfm, skip, n, c1, c2, cout) in enumerate(stages):
             cs = skip.shape[-1]
             cat = cats[l]

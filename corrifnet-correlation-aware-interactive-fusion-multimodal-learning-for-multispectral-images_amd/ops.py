@@ -136,9 +136,12 @@ def conv3_patch_wgrad(x, ldx, gy, ldg, gwp, B, S, O, Ci, Co, clamp, dev):
     check(lib().corrif_conv3_patch_wgrad(q, stream()), "corrif_conv3_patch_wgrad")
 
 
+USE_PATCH = True      # diagnostics: False routes the narrow 3x3x3 layers through the implicit-GEMM kernels instead of the patch kernels
+
+
 def _patch_cc(k, stride, pad, Ci, Co):
     """channel chunk of the patch-staged 3x3x3 kernel for this layer, 0 = use the implicit GEMM"""
-    if k != (3, 3, 3) or stride != (1, 1, 1) or pad != (1, 1, 1):
+    if not USE_PATCH or k != (3, 3, 3) or stride != (1, 1, 1) or pad != (1, 1, 1):
         return 0
     return lib().corrif_conv3_patch_cc(Ci, Co)
 
@@ -218,7 +221,7 @@ class ConvFn(Function):
         if stem:
             Kp = (T + 3) // 4 * 4
             wp = repack(weight, (Co, Kp), Co, 1, T, 0, Kp, zero=True)
-            geom = H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad, ntaps=T, src_batch_pitch=batch_pitch)
+            geom = H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad, clamp=replicate, ntaps=T, src_batch_pitch=batch_pitch)
             gemm(P(x), 1, P(wp), Kp, 0, P(y), ldc, M, Co, Kp, 1, geom, bias=P(bias) if bias is not None else None, act=act)
         elif is_gemm and act == ACT_NONE and lib().corrif_conv1x1_small_supported(Ci, Co):
             check(lib().corrif_conv1x1_small_fwd(P(x), lda, P(weight), 0, P(bias), P(y), ldc, M, Ci, Co, stream()), "corrif_conv1x1_small_fwd")
@@ -276,11 +279,14 @@ class ConvFn(Function):
             else:
                 wd = weight if T == 1 else repack(weight, (T * Co, Ci), Co, Ci, T, 1, T * Ci)
                 if replicate:  # gradient on the replicate-padded grid, then fold the halo back (adjoint of the clamp)
-                    assert stride == (1, 1, 1) and pad == (1, 1, 1)
+                    assert pad == (1, 1, 1)
                     Rg = (Di + 2, Hi + 2, Wi + 2)
                     gxp = torch.empty((B,) + Rg + (Ci,), dtype=torch.float32, device=dev)
-                    geom = H.conv_geom(Rg, (Do, Ho, Wo), (kd, kh, kw), (1, 1, 1), (0, 0, 0), transposed=True)
-                    gemm(P(gy), ldg, P(wd), Ci, 1, P(gxp), Ci, B * Rg[0] * Rg[1] * Rg[2], Ci, T * Co, Co, geom)
+                    if stride == (1, 1, 1):
+                        geom = H.conv_geom(Rg, (Do, Ho, Wo), (kd, kh, kw), (1, 1, 1), (0, 0, 0), transposed=True)
+                        gemm(P(gy), ldg, P(wd), Ci, 1, P(gxp), Ci, B * Rg[0] * Rg[1] * Rg[2], Ci, T * Co, Co, geom)
+                    else:          # strided (MMVit2's down-sampling convs): a pad-0 strided conv of the padded grid, by parity classes
+                        _dgrad_parity_classes(gy, ldg, wd, gxp, B, Rg, (Do, Ho, Wo), (kd, kh, kw), stride, (0, 0, 0), Ci, Co)
                     check(lib().corrif_pad_fold(P(gxp), P(gx), Ci, B, Di, Hi, Wi, Ci, stream()), "corrif_pad_fold")
                 elif stride != (1, 1, 1):
                     _dgrad_parity_classes(gy, ldg, wd, gx, B, (Di, Hi, Wi), (Do, Ho, Wo), (kd, kh, kw), stride, pad, Ci, Co)
@@ -298,7 +304,7 @@ class ConvFn(Function):
             if stem:
                 Kp = (T + 3) // 4 * 4
                 gwp = torch.empty((Co, Kp), dtype=torch.float32, device=dev)
-                geom = H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad, ntaps=T, src_batch_pitch=batch_pitch)
+                geom = H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad, clamp=replicate, ntaps=T, src_batch_pitch=batch_pitch)
                 wgrad(P(gy), ldg, P(x), 1, 1, P(gwp), Kp, M, Co, Kp, geom, dev)
                 gw = repack(gwp, weight.shape, Co, 1, T, 2, Kp)
             elif T == 1:
@@ -307,7 +313,7 @@ class ConvFn(Function):
                 wgrad(P(gy), ldg, P(x), lda, Ci, P(gw), Ci, M, Co, Ci, geom, dev)
             else:
                 gwp = torch.empty((Co, T * Ci), dtype=torch.float32, device=dev)
-                if (kd, kh, kw) == (3, 3, 3) and stride == (1, 1, 1) and pad == (1, 1, 1) and lib().corrif_conv3_patch_wgrad_slots(Ci, Co):
+                if USE_PATCH and (kd, kh, kw) == (3, 3, 3) and stride == (1, 1, 1) and pad == (1, 1, 1) and lib().corrif_conv3_patch_wgrad_slots(Ci, Co):
                     conv3_patch_wgrad(P(x), lda, P(gy), ldg, P(gwp), B, (Di, Hi, Wi), (Do, Ho, Wo), Ci, Co, replicate, dev)
                 else:
                     geom = H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad, clamp=replicate)
@@ -789,6 +795,36 @@ class CatChannelsFn(Function):
 
 def cat_channels(buf, *parts):
     return CatChannelsFn.apply([buf], *parts)
+
+
+class CatChannelsCopyFn(Function):
+    """torch.cat(parts, dim=channels) of channels-last tensors produced elsewhere (one strided copy per part);
+    backward hands out channel-slice views of the gradient."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        ctx.widths = [p.shape[-1] for p in parts]
+        lead = parts[0].shape[:-1]
+        out = torch.empty(lead + (sum(ctx.widths),), dtype=torch.float32, device=parts[0].device)
+        rows, C, o = out.numel() // out.shape[-1], out.shape[-1], 0
+        for p_ in parts:
+            p_, _, ld = rows_view(p_)
+            w = p_.shape[-1]
+            check(lib().corrif_copy2d(P(p_), ld, out.data_ptr() + 4 * o, C, rows, w, 0, stream()), "corrif_copy2d")
+            o += w
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, o = [], 0
+        for w in ctx.widths:
+            outs.append(g[..., o:o + w])
+            o += w
+        return tuple(outs)
+
+
+def cat_channels_copy(*parts):
+    return CatChannelsCopyFn.apply(*parts)
 
 
 class SplitBatchFn(Function):

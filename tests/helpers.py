@@ -100,6 +100,23 @@ NOGRAD_PREFIXES = ("RGB_decode_conv.", "NIR_decode_conv.", "SWIR_decode_conv.", 
                    "decoder_fuse.seg_d3.", "decoder_fuse.seg_d4.", "decoder_fuse.seg_layer.", "fusion5.conv.")
 
 
+# the same for the sibling model MMVit2
+GRAD_KEYS_MMVIT2 = [
+    "RGB_encoder.e1_c1.weight", "RGB_encoder.e1_c1.bias", "RGB_encoder.e1_c2.conv.weight", "RGB_encoder.e1_c3.conv.bias",
+    "NIR_encoder.e2_c1.conv.weight", "NIR_encoder.e2_c3.conv.weight", "SWIR_encoder.e3_c1.conv.weight", "SWIR_encoder.e4_c1.conv.bias",
+    "SWIR_encoder.e5_c1.conv.weight", "SWIR_encoder.e5_c3.conv.weight", "RGB_encoder.conv.weight", "NIR_encoder.conv.bias",
+    "RGB_encode_conv.weight", "RGB_pos", "SWIR_pos", "NIR_transformer.cross_attention_list.0.fn.fn.qkv.weight",
+    "RGB_transformer.cross_ffn_list.0.fn.fn.net.3.bias", "qkv_NIR.weight", "qkv_SWIR.bias",
+    "multimodal_transformer.cross_attention_list.0.fn.fn.proj.weight", "multimodal_transformer.cross_ffn_list.0.fn.norm.weight",
+    "multimodal_decode_conv.weight", "decoder_fuse.RFM5.fusion_layer.1.conv.weight", "decoder_fuse.RFM1.fusion_layer.0.conv.weight",
+    "decoder_fuse.d4_c1.conv.weight", "decoder_fuse.d4_c2.conv.weight", "decoder_fuse.d3_c1.conv.bias", "decoder_fuse.d2_c2.conv.weight",
+    "decoder_fuse.d1_c1.conv.weight", "decoder_fuse.d1_c2.conv.weight", "decoder_fuse.d1_out.conv.weight", "decoder_fuse.final_conv.weight",
+    "decoder_fuse.final_conv.bias",
+]
+NOGRAD_PREFIXES_MMVIT2 = ("RGB_decode_conv.", "NIR_decode_conv.", "SWIR_decode_conv.", "decoder_fuse.seg_d1.", "decoder_fuse.seg_d2.",
+                          "decoder_fuse.seg_d3.", "decoder_fuse.seg_d4.", "decoder_fuse.seg_layer.")
+
+
 def make_raw_patches(N, seed=99, HW=224):
     """synthetic stand-ins for the DSTL .mat patches the reference loader reads (F8_IMAGES4.py:20-34): reflectance-like floats"""
     import numpy as np

@@ -1,0 +1,116 @@
+"""GPU end-to-end parity of the drop-in MMVit2 (HIP kernels) against the fixtures captured from the
+upstream reference's mmmvit2.py and against the CPU oracle run on the spot.  Bracketed fp32 tolerances as for MMVit4."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+META = json.load(open(os.path.join(helpers.GOLDEN, "meta_mmvit2.json")))
+CASES = {c["name"]: c for c in META["cases"]}
+
+
+def sample(t, n=64):
+    f = t.detach().reshape(-1)
+    n = min(n, f.numel())
+    idx = (torch.arange(n, dtype=torch.int64, device=f.device) * (f.numel() - 1)) // max(n - 1, 1)
+    return f[idx].double().cpu().numpy()
+
+
+def run_hip(case):
+    import mmvit2
+    import ops
+    model = mmvit2.MMVit2()
+    sd = helpers.make_state_dict(model.state_dict(), seed=case["wseed"], conv_gain=case["conv_gain"])
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    for m in model.modules():                           # train-nodrop: dropout probability 0
+        if isinstance(getattr(m, "p", None), float):
+            m.p = 0.0
+    x, mask = helpers.make_inputs(case["B"], case["D"], case["H"], case["W"])
+    pred = model(x.to(DEV))
+    loss = ops.bce_with_logits_mean(pred, mask.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    return model, pred, mask, loss, sd
+
+
+def test_state_dict_is_the_reference_inventory():
+    import mmvit2
+    inv = json.load(open(os.path.join(helpers.GOLDEN, "state_dict_inventory_mmvit2.json")))
+    sd = mmvit2.MMVit2().state_dict()
+    assert list(sd.keys()) == list(inv.keys())
+    for k, v in sd.items():
+        assert list(v.shape) == inv[k][0], k
+
+
+@pytest.mark.parametrize("name", ["mm2_b2_d4_32", "mm2_b1_d3_40x24"])
+def test_against_reference_fixture(name):
+    case = CASES[name]
+    g = np.load(os.path.join(helpers.GOLDEN, name + ".npz"))
+    model, pred, mask, loss, _ = run_hip(case)
+    ps = pred.detach()[:, :, 0, ::4, ::4].double().cpu().numpy()
+    gap = np.abs(g["f32/pred_sample"] - g["f64/pred_sample"]).max()          # the reference's own fp32-vs-fp64 error
+    assert np.abs(ps - g["f64/pred_sample"]).max() < max(3 * gap, 2e-5), (np.abs(ps - g["f64/pred_sample"]).max(), gap)
+    assert abs(loss.item() - float(g["f64/loss"])) < max(1e-5, 3 * abs(float(g["f32/loss"]) - float(g["f64/loss"])))
+    params = dict(model.named_parameters())
+    for k in helpers.GRAD_KEYS_MMVIT2:
+        ref = g["f64/grad_sample/" + k]
+        got = sample(params[k].grad)
+        scale = max(np.abs(ref).max(), 1e-12)
+        err = np.abs(got - ref).max() / scale
+        ref32 = np.abs(g["f32/grad_sample/" + k] - ref).max() / scale
+        # 5e-3, not 1e-3: see test_full_gradient_against_oracle (ReLU mask flips under a gradient concentrated in few voxels)
+        assert err < max(5e-3, 10 * ref32), (k, err, ref32)
+        nr = float(g["f64/grad_norm/" + k])
+        n32 = abs(float(g["f32/grad_norm/" + k]) - nr)
+        assert abs(params[k].grad.double().norm().item() - nr) < max(1e-2 * nr, 10 * n32) + 1e-9, k
+    nog = [k for k, p in params.items() if p.grad is None]
+    assert len(nog) == int(g["f32/nograd_count"]) and all(k.startswith(helpers.NOGRAD_PREFIXES_MMVIT2) for k in nog)
+
+
+def test_full_gradient_against_oracle():
+    """EVERY parameter gradient against the CPU oracle (fp64 = truth, fp32 = the reference's arithmetic): per parameter the HIP
+    path's rel-L2 error vs fp64 must be <= 3x the fp32 oracle's own error, with a floor of 5e-3 per tensor and 5e-4 on the whole
+    gradient vector.  Why the per-tensor floor is not tighter: the output reads only depth slice 0 of the 128^3 decoder grid, so
+    the gradient of the last decoder levels sits in a few voxels; where a conv output feeding ReLU -> InstanceNorm is within fp32
+    noise of zero the ReLU mask flips, and ONE flipped voxel that carries a large gradient moves a whole weight gradient by ~1e-3
+    (tools/diag_mmvit2.py: 100 % of the error energy sits on flipped masks; the fp32 reference flips other voxels)."""
+    from oracle import mmvit2_oracle as O2
+    from oracle import mmvit4_oracle as O
+    case = dict(B=1, D=4, H=24, W=40, conv_gain=1.0, wseed=12)
+    model, pred, mask, loss, sd = run_hip(case)
+    x, _ = helpers.make_inputs(case["B"], case["D"], case["H"], case["W"])
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        ref = O2.MMVit2()
+        ref.load_state_dict(sd)
+        ref = ref.to(dt).train()
+        O.set_dropout(ref, False)
+        pr = ref(x.to(dt))
+        lr = O.train_step_loss(pr, mask.to(dt))
+        lr.backward()
+        res[dt] = (pr.detach().double(), lr.item(), {k: (None if p.grad is None else p.grad.double()) for k, p in ref.named_parameters()})
+    p32, l32, g32 = res[torch.float32]
+    p64, l64, g64 = res[torch.float64]
+    gap = (p32 - p64).abs().max().item()
+    assert (pred.detach().cpu().double() - p64).abs().max().item() < max(3 * gap, 2e-5)
+    assert abs(loss.item() - l64) < max(3 * abs(l32 - l64), 2e-6)
+    bad, num_h, num_r, den_all = [], 0.0, 0.0, 0.0
+    for k, p in model.named_parameters():
+        if g64[k] is None:
+            assert p.grad is None, k
+            continue
+        den = g64[k].norm().item() + 1e-30
+        d_hip = (p.grad.detach().cpu().double() - g64[k]).norm().item()
+        d_ref = (g32[k] - g64[k]).norm().item()
+        num_h, num_r, den_all = num_h + d_hip ** 2, num_r + d_ref ** 2, den_all + den ** 2
+        if d_hip / den > max(3 * d_ref / den, 5e-3):
+            bad.append((k, d_hip / den, d_ref / den))
+    assert not bad, bad[:10]
+    assert (num_h / den_all) ** 0.5 < max(3 * (num_r / den_all) ** 0.5, 5e-4), ((num_h / den_all) ** 0.5, (num_r / den_all) ** 0.5)
