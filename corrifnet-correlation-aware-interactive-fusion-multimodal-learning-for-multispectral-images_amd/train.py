@@ -122,6 +122,43 @@ def evaluate(model, loader, device):
     return sum(losses) / max(len(losses), 1), jI / max(total, 1)
 
 
+class GraphedForward:
+    """Eval-mode forward captured ONCE per input shape in a HIP graph and replayed (the per-image metric loop runs at batch 1,
+    where the ~2000 launches of a forward cost more host time than the GPU needs: a step is launch-bound, not MFMA-bound).
+    The module's multi-stream schedule is switched off for the capture: one stream needs no `record_stream` bookkeeping (which the
+    caching allocator cannot honour for a graph's private pool), and at batch 1 there is nothing to overlap anyway.  Results are
+    bit-identical to the eager forward (same kernels in the same per-tensor order)."""
+
+    def __init__(self, model, example, warmup=2):
+        model.eval()
+        self.model = model
+        self.static_in = example.detach().clone()
+        saved = []
+        for obj, name, off in ((model, "concurrent_branches", False), (model, "decoder_split", 0),
+                               (getattr(model, "decoder_fuse", None), "concurrent_skips", False)):
+            if obj is not None and hasattr(obj, name):
+                saved.append((obj, name, getattr(obj, name)))
+                setattr(obj, name, off)
+        try:
+            side = torch.cuda.Stream(device=example.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():      # lazy initialisation (kernel attributes, allocator pool) outside the capture
+                for _ in range(warmup):
+                    model(self.static_in)
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self.static_out = model(self.static_in)
+        finally:
+            for obj, name, val in saved:
+                setattr(obj, name, val)
+
+    def __call__(self, x):
+        self.static_in.copy_(x)
+        self.graph.replay()
+        return self.static_out
+
+
 @torch.no_grad()
 def per_image_metrics(model, images, masks):
     """Jaccard2 and F1 per image at batch 1 (allJaccardResults_irem_f1_jcrd.py:201-222); returns two lists of floats"""

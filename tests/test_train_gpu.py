@@ -143,3 +143,20 @@ def test_reducer_rccl_path_single_rank():
         assert len(red.buckets) > 5 and red.communicated_elements() == 85343883      # the 18 grad-less tensors never travel
     finally:
         dist.destroy_process_group()
+
+
+def test_hip_graph_eval_forward_is_bit_identical_to_eager():
+    """train.GraphedForward: the eval forward captured in a HIP graph (batch-1 metric loop) replays to the eager result,
+    also for a second input written into the static buffer, and leaves the module's multi-stream switches untouched."""
+    import train
+    _, hip = _models(seed=21, train=False)
+    x1, _ = helpers.make_inputs(1, 3, 64, 64, seed=1)
+    x2, _ = helpers.make_inputs(1, 3, 64, 64, seed=2)
+    x1, x2 = x1.to(DEV), x2.to(DEV)
+    with torch.no_grad():
+        e1, e2 = hip(x1).clone(), hip(x2).clone()
+    g = train.GraphedForward(hip, x1)
+    assert hip.concurrent_branches and hip.decoder_split == 2 and hip.decoder_fuse.concurrent_skips
+    assert torch.equal(g(x1), e1)
+    assert torch.equal(g(x2), e2)
+    assert torch.equal(g(x1), e1)
