@@ -1,5 +1,6 @@
+"""Diagnostic (GPU box): the narrow 3x3x3 layers through the implicit-GEMM kernels instead of the patch kernels (ops.USE_PATCH = False)."""
 import os, sys, math
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests")); import helpers  # noqa
 import torch, torch.nn.functional as F, ops
 import test_kernels_gpu as T

@@ -1,5 +1,7 @@
+"""Diagnostic (GPU box, uses the oracle: test infrastructure): where does the MMVit2 decoder-gradient error vs fp64 come from?
+Answer: ReLU mask flips at voxels whose conv output is within fp32 noise of zero - see tests/test_mmvit2_gpu.py."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests")); import helpers  # noqa
 import torch, mmvit2, ops
 from oracle import mmvit2_oracle as O2

@@ -80,7 +80,7 @@ def test_full_gradient_against_oracle():
     gradient vector.  Why the per-tensor floor is not tighter: the output reads only depth slice 0 of the 128^3 decoder grid, so
     the gradient of the last decoder levels sits in a few voxels; where a conv output feeding ReLU -> InstanceNorm is within fp32
     noise of zero the ReLU mask flips, and ONE flipped voxel that carries a large gradient moves a whole weight gradient by ~1e-3
-    (tools/diag_mmvit2.py: 100 % of the error energy sits on flipped masks; the fp32 reference flips other voxels)."""
+    (tests/diag/diag_mmvit2_relu_flips.py: 100 % of the error energy sits on flipped masks; the fp32 reference flips other voxels)."""
     from oracle import mmvit2_oracle as O2
     from oracle import mmvit4_oracle as O
     case = dict(B=1, D=4, H=24, W=40, conv_gain=1.0, wseed=12)
