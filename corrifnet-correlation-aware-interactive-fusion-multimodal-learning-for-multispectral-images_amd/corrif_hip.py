@@ -134,7 +134,7 @@ def lib():
             fn = getattr(l, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if l.corrif_abi_version() != 1:
+        if l.corrif_abi_version() != 2:
             raise RuntimeError("corrif: ABI version mismatch")
         _lib = l
     return _lib

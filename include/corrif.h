@@ -32,7 +32,7 @@ extern "C" {
 #define CORRIF_EUNSUPPORTED (-2)
 #define CORRIF_ELAUNCH (-3)
 
-#define CORRIF_ABI_VERSION 1
+#define CORRIF_ABI_VERSION 2   /* 2: CorrifConv3Patch.fold */
 int corrif_abi_version(void);
 /* name of the gfx target the library was built for ("gfx950") - host-only call */
 const char* corrif_build_arch(void);
