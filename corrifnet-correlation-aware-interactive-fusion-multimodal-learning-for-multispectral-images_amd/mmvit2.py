@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 import ops
-from mmvit4 import (Conv3dP, Decoder_fuse, Transformer, _MODS, basic_dims, depth, general_conv3d_prenorm, mlp_dim, num_heads,
+from mmvit4 import (_rs, Conv3dP, Decoder_fuse, Transformer, _MODS, basic_dims, depth, general_conv3d_prenorm, mlp_dim, num_heads,
                     num_modals, patch_size, transformer_basic_dims)
 
 
@@ -88,14 +88,14 @@ class MMVit2(nn.Module):
             for i, m in enumerate(_MODS):
                 st = self._streams[i]
                 st.wait_stream(cur)
-                x.record_stream(st)
+                _rs(x, st)
                 with torch.cuda.stream(st):
                     branch(i, m)
             for st in self._streams:
                 cur.wait_stream(st)
             for i in range(num_modals):
                 for t in feats[i] + [qkv[i]]:
-                    t.record_stream(cur)
+                    _rs(t, cur)
         else:
             for i, m in enumerate(_MODS):
                 branch(i, m)

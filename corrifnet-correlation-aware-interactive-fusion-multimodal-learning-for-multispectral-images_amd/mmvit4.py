@@ -28,6 +28,14 @@ patch_size = 8
 _MODS = ("RGB", "NIR", "SWIR")
 
 
+def _rs(t, stream):
+    """tensor.record_stream(stream) for tensors that cross streams - except while a HIP graph is being captured: the caching
+    allocator cannot honour it for a graph's private pool (its deferred-free events are capture nodes), and inside one captured
+    forward every cross-stream tensor is held by the forward's own locals until all forked streams have re-joined."""
+    if not torch.cuda.is_current_stream_capturing():
+        t.record_stream(stream)
+
+
 def _triple(v):
     return (v, v, v) if isinstance(v, int) else tuple(v)
 
@@ -259,7 +267,7 @@ class Decoder_fuse(nn.Module):
                 side = self._side[lane] = torch.cuda.Stream(device=dev)
             side.wait_stream(cur)
             for t in (x1, x2, x3, x4) + tuple(cats):      # allocated on the caller's stream, used (and saved) on the side stream
-                t.record_stream(side)
+                _rs(t, side)
             events = []
             with torch.cuda.stream(side):
                 for l, (rfm, skip, n, _, _, _) in enumerate(stages):
@@ -278,7 +286,7 @@ class Decoder_fuse(nn.Module):
             part_y = c1(up, out=cat[..., cs:])                                 # d*_c1: 3x3x3 replicate -> ReLU -> IN
             if use_side:
                 torch.cuda.current_stream().wait_event(events[l])
-                parts_s[l].record_stream(torch.cuda.current_stream())
+                _rs(parts_s[l], torch.cuda.current_stream())
             else:
                 parts_s[l] = ops.nearest(rfm(skip), (n, n, n), out=cat[..., :cs])
             y = cout(c2(ops.cat_channels(cat, parts_s[l], part_y)))
@@ -446,16 +454,16 @@ class MMVit4(nn.Module):
                 st.wait_stream(cur)
                 # tensors allocated on the caller's stream that this branch reads / writes (also from its saved-for-backward
                 # state): tell the caching allocator, or their memory could be re-used while the branch stream still needs it
-                x.record_stream(st)
+                _rs(x, st)
                 for c in cats:
-                    c.record_stream(st)
+                    _rs(c, st)
                 with torch.cuda.stream(st):
                     branch(i, m)
             for st in self._streams:
                 cur.wait_stream(st)
             for i in range(num_modals):        # branch outputs are consumed on the caller's stream from here on
                 for t in feats[i] + [skip[i], qkv[i]]:
-                    t.record_stream(cur)
+                    _rs(t, cur)
         else:
             for i, m in enumerate(_MODS):
                 branch(i, m)
@@ -488,14 +496,14 @@ class MMVit4(nn.Module):
         for k in range(lanes):
             st = self._dec_streams[k]
             st.wait_stream(cur)
-            pos.record_stream(st)
+            _rs(pos, st)
             for t in ins:
-                t[k].record_stream(st)
+                _rs(t[k], st)
             with torch.cuda.stream(st):
                 outs.append(tail(*[t[k] for t in ins], lane=k))
         for k in range(lanes):
             cur.wait_stream(self._dec_streams[k])
-            outs[k].record_stream(cur)
+            _rs(outs[k], cur)
         return ops.cat_batch(*outs)
 
 

@@ -125,9 +125,10 @@ def evaluate(model, loader, device):
 class GraphedForward:
     """Eval-mode forward captured ONCE per input shape in a HIP graph and replayed (the per-image metric loop runs at batch 1,
     where the ~2000 launches of a forward cost more host time than the GPU needs: a step is launch-bound, not MFMA-bound).
-    The module's multi-stream schedule is switched off for the capture: one stream needs no `record_stream` bookkeeping (which the
-    caching allocator cannot honour for a graph's private pool), and at batch 1 there is nothing to overlap anyway.  Results are
-    bit-identical to the eager forward (same kernels in the same per-tensor order)."""
+    The module's multi-stream schedule is switched off for the capture (one stream; at batch 1 there is little to overlap).
+    Capturing the forked branch / lane / skip streams as well replays 1.9x faster than eager at batch 1 and is bit-identical,
+    but the process then segfaults inside the HIP runtime on the next eager forward or capture (observed twice on the MI355X
+    boxes, with and without `record_stream`), so it is not offered.  Results are bit-identical to the eager forward."""
 
     def __init__(self, model, example, warmup=2):
         model.eval()
@@ -142,10 +143,11 @@ class GraphedForward:
         try:
             side = torch.cuda.Stream(device=example.device)
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side), torch.no_grad():      # lazy initialisation (kernel attributes, allocator pool) outside the capture
+            with torch.cuda.stream(side), torch.no_grad():      # lazy initialisation (kernel attributes, streams, allocator pool) outside the capture
                 for _ in range(warmup):
                     model(self.static_in)
             torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(self.graph):
                 self.static_out = model(self.static_in)

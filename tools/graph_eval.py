@@ -16,6 +16,9 @@ for B in (1, 4):
     g = train.GraphedForward(model, x)
     out = g(x); torch.cuda.synchronize()
     same = torch.equal(out, ref)
+    x2 = torch.randn_like(x)
+    with torch.no_grad(): ref2 = model(x2).clone()
+    same = same and torch.equal(g(x2), ref2) and torch.equal(g(x), ref)
     t0 = time.perf_counter()
     for _ in range(10): out = g(x)
     torch.cuda.synchronize(); graphed = (time.perf_counter() - t0) / 10
