@@ -147,8 +147,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("CORRIF_DIST_BACKEND", "nccl")     # "gloo": control-flow rehearsal of N ranks on a box with fewer GPUs
+        local = local % torch.cuda.device_count() if backend != "nccl" else local
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if world > 1 else 0)
@@ -199,7 +204,9 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kt_steps = 0
-    if timer and rank == 0:
+    if timer:
+        # EVERY rank runs this pass (its steps contain the gradient all-reduces: a rank-0-only pass would leave the collectives
+        # unmatched and hang the job); only rank 0 reports.
         # per-launch durations of the MFMA kernels: HIP events around every launch, in an extra pass right after the timed
         # region with the three modality branches serialised on one stream (with concurrent streams an event pair also
         # spans the other streams' kernels, so per-kernel durations are only meaningful one stream at a time)
