@@ -160,3 +160,22 @@ def test_hip_graph_eval_forward_is_bit_identical_to_eager():
     assert torch.equal(g(x1), e1)
     assert torch.equal(g(x2), e2)
     assert torch.equal(g(x1), e1)
+
+
+def test_bench_two_rank_control_flow_rehearsal():
+    """bench.py under torchrun with 2 ranks on this one GPU (gloo instead of RCCL: same code path, collectives included):
+    every rank must reach every collective - a rank-0-only section containing a gradient all-reduce would hang here."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, CORRIF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(helpers.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--batch", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["scaling"] == "weak"
+    assert out["value"] > 0 and "roofline" in out
