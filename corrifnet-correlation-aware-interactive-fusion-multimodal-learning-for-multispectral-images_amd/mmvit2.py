@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 import ops
-from mmvit4 import (_rs, Conv3dP, Decoder_fuse, Transformer, _MODS, basic_dims, depth, general_conv3d_prenorm, mlp_dim, num_heads,
+from mmvit4 import (_rs, _run_lanes, Conv3dP, Decoder_fuse, Transformer, _MODS, basic_dims, depth, general_conv3d_prenorm, mlp_dim, num_heads,
                     num_modals, patch_size, transformer_basic_dims)
 
 
@@ -66,7 +66,9 @@ class MMVit2(nn.Module):
         self.multimodal_decode_conv = Conv3dP(T * num_modals, d8 * num_modals, 1)
         self.decoder_fuse = Decoder_fuse(num_cls=num_cls, reduce5=False)
         self.concurrent_branches = True
+        self.decoder_split = 2          # sample-group lanes from the multimodal transformer on (see mmvit4._run_lanes)
         self._streams = None
+        self._dec_streams = None
 
     def forward(self, x):
         if not x.is_cuda:
@@ -103,6 +105,11 @@ class MMVit2(nn.Module):
         skips = [ops.cat_channels_copy(*[feats[i][l] for i in range(num_modals)]) for l in range(4)]
         corr = ops.inter_corr(qkv[0], qkv[1], qkv[2])                                      # mmmvit2.py:440-453
         pos = ops.cat_tokens(self.RGB_pos, self.NIR_pos, self.SWIR_pos)
-        y = self.multimodal_transformer(ops.cat_tokens(*corr), pos)                        # [B, 1536, 512]
-        x6 = self.multimodal_decode_conv(y.view(B, P3, P3, P3, num_modals * T))            # 3 tokens -> one voxel (mmmvit2.py:470)
-        return self.decoder_fuse(skips[0], skips[1], skips[2], skips[3], x6)
+
+        def tail(tok, s1, s2, s3, s4, lane=0):
+            nb = tok.shape[0]
+            y = self.multimodal_transformer(tok, pos)                                      # [nb, 1536, 512]
+            x6 = self.multimodal_decode_conv(y.view(nb, P3, P3, P3, num_modals * T))       # 3 tokens -> one voxel (mmmvit2.py:470)
+            return self.decoder_fuse(s1, s2, s3, s4, x6, lane=lane)
+
+        return _run_lanes(self, tail, pos, ops.cat_tokens(*corr), skips[0], skips[1], skips[2], skips[3])

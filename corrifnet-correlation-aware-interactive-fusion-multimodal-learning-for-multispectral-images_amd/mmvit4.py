@@ -481,30 +481,36 @@ class MMVit4(nn.Module):
             x6 = self.multimodal_decode_conv(y.view(nb, P3, P3, P3, 4 * T))                # 4 tokens -> one voxel (mmvit4.py:526)
             return self.decoder_fuse(f1, f2, f3, f4, x6, lane=lane)
 
-        lanes = min(int(self.decoder_split), B) if self.decoder_split else 1
-        if lanes < 2:
-            return tail(tokens, fused[0], fused[1], fused[2], fused[3])
-        # Everything after the inter-modal correlation is per sample: the multimodal transformer and the decoder run as `lanes`
-        # sample-group chains on separate streams, so one chain's softmax / LayerNorm / InstanceNorm / resampling passes overlap the
-        # other's matrix work (the transformer alone is a single chain with ~10 ms of exposed HBM-bound passes per step).
-        cur = torch.cuda.current_stream()
-        if self._dec_streams is None or len(self._dec_streams) < lanes:
-            self._dec_streams = [torch.cuda.Stream(device=x.device) for _ in range(lanes)]
-        bounds = [B * k // lanes for k in range(lanes + 1)]
-        ins = [ops.split_batch(t, bounds) for t in (tokens, fused[0], fused[1], fused[2], fused[3])]
-        outs = []
-        for k in range(lanes):
-            st = self._dec_streams[k]
-            st.wait_stream(cur)
-            _rs(pos, st)
-            for t in ins:
-                _rs(t[k], st)
-            with torch.cuda.stream(st):
-                outs.append(tail(*[t[k] for t in ins], lane=k))
-        for k in range(lanes):
-            cur.wait_stream(self._dec_streams[k])
-            _rs(outs[k], cur)
-        return ops.cat_batch(*outs)
+        return _run_lanes(self, tail, pos, tokens, fused[0], fused[1], fused[2], fused[3])
+
+
+def _run_lanes(model, tail, shared, *per_sample):
+    """Everything after the inter-modal correlation is per sample: the multimodal transformer and the decoder run as
+    `model.decoder_split` sample-group chains ("lanes") on separate streams, so one chain's softmax / LayerNorm / InstanceNorm /
+    resampling passes overlap the other's matrix work.  tail(*tensors, lane=k) -> prediction of that sample group; `shared` is a
+    tensor every lane reads (the positional embedding)."""
+    B = per_sample[0].shape[0]
+    lanes = min(int(model.decoder_split), B) if model.decoder_split else 1
+    if lanes < 2:
+        return tail(*per_sample)
+    cur = torch.cuda.current_stream()
+    if model._dec_streams is None or len(model._dec_streams) < lanes:
+        model._dec_streams = [torch.cuda.Stream(device=per_sample[0].device) for _ in range(lanes)]
+    bounds = [B * k // lanes for k in range(lanes + 1)]
+    ins = [ops.split_batch(t, bounds) for t in per_sample]
+    outs = []
+    for k in range(lanes):
+        st = model._dec_streams[k]
+        st.wait_stream(cur)
+        _rs(shared, st)
+        for t in ins:
+            _rs(t[k], st)
+        with torch.cuda.stream(st):
+            outs.append(tail(*[t[k] for t in ins], lane=k))
+    for k in range(lanes):
+        cur.wait_stream(model._dec_streams[k])
+        _rs(outs[k], cur)
+    return ops.cat_batch(*outs)
 
 
 def Jaccard2(y, y_pred, epsilon=1e-8):

@@ -7,6 +7,7 @@ dev = "cuda:0"
 B = int(os.environ.get("B", "16"))
 torch.manual_seed(0)
 model = mmvit2.MMVit2().to(dev).train()
+if os.environ.get("SPLIT") is not None: model.decoder_split = int(os.environ["SPLIT"])
 x, mask = helpers.make_inputs(B, 4, 224, 224); x, mask = x.to(dev), mask.to(dev)
 def step():
     model.zero_grad(set_to_none=True)
