@@ -94,6 +94,17 @@ class MfmaTimer:
         v = sorted(a.elapsed_time(b) for a, b in ds)
         return v[len(v) // 2]
 
+    def by_kind(self, overhead_ms=0.0, steps=1):
+        """per kernel family: ms per step and achieved TFLOP/s (conv / dgrad / gemm = gemm_fwd_kernel in its three roles)"""
+        agg = {}
+        for fl, e0, e1, key in self.rec:
+            d = agg.setdefault(key[0], [0.0, 0.0, 0])
+            d[0] += max(e0.elapsed_time(e1) - overhead_ms, 0.0)
+            d[1] += fl
+            d[2] += 1
+        return {k: {"ms_per_step": round(v[0] / steps, 2), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0.0,
+                    "launches_per_step": v[2] // steps} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+
     def summary(self, overhead_ms=0.0):
         fl = sum(r[0] for r in self.rec)
         ms = sum(max(r[1].elapsed_time(r[2]) - overhead_ms, 0.0) for r in self.rec)
@@ -266,6 +277,7 @@ def main():
                                "method": "HIP events around each MFMA launch (weight gradients incl. their fixed-order slab reduce), %d extra "
                                          "single-stream steps after the timed region; the empty-event-pair time is subtracted per launch" % kt_steps,
                                "event_pair_overhead_us": round(ovh * 1e3, 2),
+                               "families": timer.by_kind(ovh, max(kt_steps, 1)),
                                "whole_step_frac": round(FLOP_PER_IMAGE_FWD_BWD * B / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
         if timer and args.dump_shapes:
             with open(args.dump_shapes, "w") as f:
