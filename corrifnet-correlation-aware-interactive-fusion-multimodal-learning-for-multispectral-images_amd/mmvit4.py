@@ -412,6 +412,7 @@ class MMVit4(nn.Module):
         # of the other.  Forward values are unchanged; decoder weight gradients become the sum of two half-batch reductions.
         self.decoder_split = 2          # number of sample groups (0 / 1 = off)
         self._dec_streams = None
+        self.auto_streams = True        # single-stream schedule when the step's autograd state nears the HBM capacity
 
     @staticmethod
     def _level_shapes(B, D, H, W):
@@ -430,6 +431,21 @@ class MMVit4(nn.Module):
             raise RuntimeError("MMVit4 (MI355X build) runs on the GPU only: there is no CPU fall-back path")
         if x.dtype != torch.float32 or x.dim() != 5 or x.shape[1] != num_modals:
             raise ValueError("expected fp32 input [B, 3, D, H, W]")
+        B = x.shape[0]
+        P3, T = patch_size, transformer_basic_dims
+        if self.auto_streams and torch.is_grad_enabled() and _memory_limited(x):
+            # Near the HBM capacity the multi-stream schedule back-fires: the caching allocator keeps one pool PER STREAM, so blocks
+            # cached by one stream cannot serve another and the step degenerates into hipFree / hipMalloc retries (measured at
+            # B=64, 8 bands, 256^2 = 250 GB of autograd state: 10.4 s per step on seven streams, 1.16 s on one).
+            saved = (self.concurrent_branches, self.decoder_split, self.decoder_fuse.concurrent_skips)
+            self.concurrent_branches, self.decoder_split, self.decoder_fuse.concurrent_skips = False, 0, False
+            try:
+                return self._forward(x)
+            finally:
+                self.concurrent_branches, self.decoder_split, self.decoder_fuse.concurrent_skips = saved
+        return self._forward(x)
+
+    def _forward(self, x):
         B = x.shape[0]
         P3, T = patch_size, transformer_basic_dims
         # early-fusion concat buffers, allocated up front on the caller's stream (the branches fill their channel slices)
@@ -482,6 +498,15 @@ class MMVit4(nn.Module):
             return self.decoder_fuse(f1, f2, f3, f4, x6, lane=lane)
 
         return _run_lanes(self, tail, pos, tokens, fused[0], fused[1], fused[2], fused[3])
+
+
+def _memory_limited(x, frac=0.6):
+    """True when the autograd state of one training step is estimated to exceed `frac` of the device memory.  Fit to measured peaks
+    (B=32: 74.5 GB at 4 x 224^2, 124.5 GB at 8 x 256^2; B=64: 248 GB at 8 x 256^2): the decoder costs 1.36 GB per sample whatever the
+    input size, the three encoders 4.82 kB per input voxel."""
+    B, _, D, Hh, W = x.shape
+    est = B * (1.36e9 + 4.82e3 * D * Hh * W)
+    return est > frac * torch.cuda.get_device_properties(x.device).total_memory
 
 
 def _run_lanes(model, tail, shared, *per_sample):
