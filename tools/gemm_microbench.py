@@ -18,7 +18,7 @@ for (M, N, K) in [(4096, 4096, 4096), (25088, 1024, 256), (25088, 256, 1024), (4
     Bt = torch.randn(K, N, device=dev)
     ms = bench(lambda: ops.gemm(A.data_ptr(), K, Bt.data_ptr(), N, 1, C.data_ptr(), N, M, N, K, K, H.gemm_geom()))
     print("bl1   M %7d N %5d K %5d : %8.3f ms  %6.1f TF/s" % (M, N, K, ms, 2.0 * M * N * K / ms / 1e9), flush=True)
-for (R, M, N) in [(25088, 256, 1024), (401408, 64, 256), (100352, 128, 512), (6272, 512, 2048)]:
+for (R, M, N) in [(25088, 256, 1024), (401408, 64, 256), (100352, 128, 512), (6272, 512, 2048), (401408, 256, 64), (100352, 512, 64)]:
     dY = torch.randn(R, M, device=dev); X = torch.randn(R, N, device=dev); dW = torch.empty(M, N, device=dev)
     ms = bench(lambda: ops.wgrad(dY.data_ptr(), M, X.data_ptr(), N, N, dW.data_ptr(), N, R, M, N, H.gemm_geom(), dev))
     print("wgrad R %7d M %5d N %5d : %8.3f ms  %6.1f TF/s" % (R, M, N, ms, 2.0 * R * M * N / ms / 1e9), flush=True)
