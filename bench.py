@@ -179,6 +179,8 @@ def main():
 
     torch.manual_seed(0)
     model = mmvit4.MMVit4().to(dev).train()
+    if os.environ.get("CORRIF_GRAD_TAP") is not None:        # A/B switch
+        mmvit4.GRAD_TAP = os.environ["CORRIF_GRAD_TAP"] == "1"
     if os.environ.get("CORRIF_DECODER_SPLIT") is not None:   # A/B switch
         model.decoder_split = int(os.environ["CORRIF_DECODER_SPLIT"])
     if os.environ.get("CORRIF_SERIAL") == "1":          # profiling aid: one stream, clean per-kernel attribution

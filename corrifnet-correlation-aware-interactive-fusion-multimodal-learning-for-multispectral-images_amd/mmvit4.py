@@ -26,6 +26,7 @@ depth = 1
 num_modals = 3
 patch_size = 8
 _MODS = ("RGB", "NIR", "SWIR")
+GRAD_TAP = True       # Bottleneck identity blocks: fold the residual gradient into conv1's data-gradient epilogue (ops.grad_tap)
 
 
 def _rs(t, stream):
@@ -54,8 +55,8 @@ class Conv3dP(nn.Module):
         else:
             self.register_parameter("bias", None)
 
-    def forward(self, x, out=None, stats=None):
-        return ops.conv3d(x, self.weight, self.bias, self.stride, self.pad, self.replicate, out, stats=stats)
+    def forward(self, x, out=None, stats=None, grad_link=None):
+        return ops.conv3d(x, self.weight, self.bias, self.stride, self.pad, self.replicate, out, stats=stats, grad_link=grad_link)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%s, stride=%s, padding=%s%s%s" % (
@@ -151,14 +152,19 @@ class Bottleneck3D(nn.Module):
         def st():                                   # BatchNorm batch statistics come out of the producing GEMM's epilogue
             return {"G": 1, "relu": False} if train else None
 
-        idt = x
+        idt, link = x, None
         if self.downsample is not None:
             s0 = st()
             idt = self.downsample[1](self.downsample[0](x, stats=s0), pre=s0)
+        elif GRAD_TAP and torch.is_grad_enabled() and x.requires_grad:
+            link = {}          # identity block: x feeds conv1 AND the residual add; conv1's data-gradient epilogue absorbs the latter's gradient
         s1, s2, s3 = st(), st(), st()
-        y = self.bn1(self.conv1(x, stats=s1), relu_out=True, pre=s1)
+        y = self.bn1(self.conv1(x, stats=s1, grad_link=link), relu_out=True, pre=s1)
         y = self.bn2(self.conv2(y, stats=s2), relu_out=True, pre=s2)
-        return self.bn3(self.conv3(y, stats=s3), residual=idt, relu_out=True, pre=s3)
+        y = self.conv3(y, stats=s3)
+        if link is not None:
+            idt = ops.grad_tap(x, link)        # created after conv1..conv3's nodes: its backward runs before theirs
+        return self.bn3(y, residual=idt, relu_out=True, pre=s3)
 
 
 def _res_layer(cin, width, n, stride):

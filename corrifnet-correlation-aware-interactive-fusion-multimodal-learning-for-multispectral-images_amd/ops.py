@@ -198,7 +198,8 @@ class ConvFn(Function):
     """nn.Conv3d on channels-last activations.  weight stays in the reference (O,I,kd,kh,kw) layout."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, replicate, out, act, stats_req):
+    def forward(ctx, x, weight, bias, stride, pad, replicate, out, act, stats_req, grad_link=None):
+        ctx.grad_link = grad_link
         Co, Ci, kd, kh, kw = weight.shape
         T = kd * kh * kw
         stem = Ci == 1
@@ -262,7 +263,12 @@ class ConvFn(Function):
             if is_gemm and lib().corrif_conv1x1_small_supported(Ci, Co):
                 check(lib().corrif_conv1x1_small_fwd(P(gy), ldg, P(weight), 1, 0, P(gx), Ci, Min, Co, Ci, stream()), "corrif_conv1x1_small_fwd")
             elif is_gemm:      # dX[M,Ci] = dY[M,Co] . W[Co,Ci]   (W is the [K][N] operand as stored)
-                gemm(P(gy), ldg, P(weight), Ci, 1, P(gx), Ci, Min, Ci, Co, Co, H.gemm_geom())
+                add_p, add_ld = None, 0
+                link = ctx.grad_link
+                if link is not None and "g" in link:          # the residual branch's gradient of the same tensor (grad_tap): the GEMM
+                    ga, _, add_ld = rows_view(link.pop("g"))   # epilogue adds it, instead of a separate accumulation pass over both
+                    add_p = P(ga)
+                gemm(P(gy), ldg, P(weight), Ci, 1, P(gx), Ci, Min, Ci, Co, Co, H.gemm_geom(), addend=add_p, ld_add=add_ld)
             elif _patch_cc((kd, kh, kw), stride, pad, Co, Ci):      # data gradient = patch conv of dY with flipped weights
                 cc = _patch_cc((kd, kh, kw), stride, pad, Co, Ci)
                 wd = repack(weight, (Co // cc, Ci, T, cc), Co, Ci, T, 4, cc)
@@ -299,7 +305,8 @@ class ConvFn(Function):
             gb = torch.empty(Co, dtype=torch.float32, device=dev) if has_bias else None
             ws = _ws(lib().corrif_conv1x1_small_workspace(M, Ci, Co), dev)
             check(lib().corrif_conv1x1_small_wgrad(P(x), lda, P(gy), ldg, P(gw), P(gb), P(ws), M, Ci, Co, stream()), "corrif_conv1x1_small_wgrad")
-            return gx, gw, gb, None, None, None, None, None, None
+            gx = _finish_link(ctx.grad_link, gx)
+            return gx, gw, gb, None, None, None, None, None, None, None
         if ctx.needs_input_grad[1]:
             if stem:
                 Kp = (T + 3) // 4 * 4
@@ -321,13 +328,48 @@ class ConvFn(Function):
                 gw = repack(gwp, weight.shape, Co, Ci, T, 2, T * Ci)
         if has_bias and ctx.needs_input_grad[2]:
             gb = col_sum(gy, M, ldg, Co)
-        return gx, gw, gb, None, None, None, None, None, None
+        gx = _finish_link(ctx.grad_link, gx)
+        return gx, gw, gb, None, None, None, None, None, None, None
 
 
-def conv3d(x, weight, bias=None, stride=(1, 1, 1), pad=(0, 0, 0), replicate=False, out=None, act=ACT_NONE, stats=None):
+def _finish_link(link, gx):
+    """grad_tap bookkeeping at the end of ConvFn.backward: a tapped gradient that no kernel epilogue absorbed is added here; the
+    link is marked done so that a tap firing later falls back to ordinary autograd accumulation."""
+    if link is not None:
+        if "g" in link and gx is not None:
+            gx = add(gx, link.pop("g").contiguous())
+        link["done"] = True
+    return gx
+
+
+class GradTapFn(Function):
+    """Identity on a tensor that has a second consumer whose backward can absorb this use's gradient (the Bottleneck input feeds the
+    residual add AND conv1): backward parks the gradient in `link` for conv1's data-gradient GEMM epilogue and returns nothing,
+    which removes the separate gradient-accumulation pass (read two tensors, write one) autograd would otherwise run.  The tap's node
+    is created right before the residual add, i.e. after conv1's, so the engine runs it first; if it ever ran after conv1's backward
+    (`link["done"]`) it simply returns the gradient to autograd."""
+
+    @staticmethod
+    def forward(ctx, x, link):
+        ctx.link = link
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.link.get("done"):
+            return g, None
+        ctx.link["g"] = g
+        return None, None
+
+
+def grad_tap(x, link):
+    return GradTapFn.apply(x, link)
+
+
+def conv3d(x, weight, bias=None, stride=(1, 1, 1), pad=(0, 0, 0), replicate=False, out=None, act=ACT_NONE, stats=None, grad_link=None):
     """stats: None, or a dict {"G": groups, "relu": bool}: ask the GEMM epilogue for the statistics partials of the norm that follows;
     on success the dict gains "part" / "chunks" / "rpg" (pass it to batch_norm / relu_instnorm as `pre`)."""
-    return ConvFn.apply(x, weight, bias, tuple(stride), tuple(pad), bool(replicate), out, act, stats)
+    return ConvFn.apply(x, weight, bias, tuple(stride), tuple(pad), bool(replicate), out, act, stats, grad_link)
 
 
 # --------------------------------------------------------------------------------------- linear
