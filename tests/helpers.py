@@ -19,6 +19,14 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 
+def free_port():
+    """a free TCP port on 127.0.0.1 for a torch.distributed rendezvous (a fixed number may be taken on a shared host)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _gen(seed, key):
     g = torch.Generator()
     g.manual_seed((seed * 1000003 + zlib.crc32(key.encode())) % (2 ** 31))

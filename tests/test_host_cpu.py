@@ -171,7 +171,7 @@ def test_data_parallel_gloo_world2(built, tmp_path):
     never communicated; initial state identical after the broadcast."""
     script = tmp_path / "dp_worker.py"
     script.write_text(DP_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(helpers.free_port()), WORLD_SIZE="2")
     procs = []
     for r in range(2):
         e = dict(env, RANK=str(r))

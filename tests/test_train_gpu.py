@@ -117,7 +117,7 @@ def test_reducer_rccl_path_single_rank():
     import ops
     from data_parallel import GradAllReducer, broadcast_module_state
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29517")
+    os.environ.setdefault("MASTER_PORT", str(helpers.free_port()))
     if not dist.is_initialized():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
     try:
@@ -169,9 +169,10 @@ def test_bench_two_rank_control_flow_rehearsal():
     import os
     import subprocess
     import sys
+    port = helpers.free_port()
     env = dict(os.environ, CORRIF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(helpers.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--master-port", str(port), os.path.join(helpers.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
            "--batch", "2", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
