@@ -111,8 +111,20 @@ class MfmaTimer:
         return fl, ms, len(self.rec)
 
 
-def cpu_baseline(B=2, D=4, HW=224, iters=2):
-    """bounded sample of the same workload on the host cores: the oracle's forward + loss + backward at batch B"""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(B=4, D=4, HW=224, iters=3):
+    """Bounded sample of the same workload on the host cores (SURVEY section 8d / BASELINE.md section 3): the oracle's forward + loss +
+    backward at batch 4 (= BASELINE configs[0], the reference's own CPU-runnable case; 18.5 GB of host memory), train mode with
+    dropout on, 1 warm-up + `iters` timed steps, best and median."""
     from oracle import mmvit4_oracle as O
     import helpers
     cores = os.cpu_count() or 1
@@ -122,7 +134,9 @@ def cpu_baseline(B=2, D=4, HW=224, iters=2):
         pass
     cores = max(1, min(cores, int(os.environ.get("CORRIF_CPU_THREADS", "16"))))   # a 1-GPU box owns a 16-core CPU share
     torch.set_num_threads(cores)
-    print("[bench] timing the CPU oracle on %d host threads (B=%d, about %d fwd+bwd steps) ..." % (cores, B, iters + 1), file=sys.stderr, flush=True)
+    model_name = _cpu_model()
+    print("[bench] timing the CPU oracle on %d host threads of '%s' (B=%d, %d fwd+bwd steps) ..." % (cores, model_name, B, iters + 1),
+          file=sys.stderr, flush=True)
     torch.manual_seed(0)
     m = O.MMVit4().train()
     x, mask = helpers.make_inputs(B, D, HW, HW)
@@ -133,10 +147,12 @@ def cpu_baseline(B=2, D=4, HW=224, iters=2):
         O.train_step_loss(m(x), mask).backward()
         ts.append(time.time() - t0)
         print("[bench]   cpu step %d: %.1f s" % (i, ts[-1]), file=sys.stderr, flush=True)
-    best = min(ts[1:])
-    return {"value": round(B / best, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "oracle (CPU restatement of mmvit4.MMVit4, bit-identical to the reference on CPU) fwd+loss+bwd, "
-                      "train mode, B=%d D=%d %dx%d fp32, best of %d after 1 warm-up (%.1f s/step)" % (B, D, HW, HW, iters, best)}
+    timed = sorted(ts[1:])
+    best, med = timed[0], timed[len(timed) // 2]
+    return {"value": round(B / best, 4), "median": round(B / med, 4), "unit": "images/s", "cores": cores, "cpu": model_name, "kind": "port",
+            "sample": "oracle (CPU restatement of mmvit4.MMVit4, bit-identical to the reference on CPU) fwd+loss+bwd, train mode "
+                      "(dropout on), B=%d D=%d %dx%d fp32 (BASELINE configs[0]), 1 warm-up + %d timed steps: best %.1f s, median %.1f s "
+                      "per step" % (B, D, HW, HW, iters, best, med)}
 
 
 def main():
@@ -183,6 +199,8 @@ def main():
         mmvit4.GRAD_TAP = os.environ["CORRIF_GRAD_TAP"] == "1"
     if os.environ.get("CORRIF_DECODER_SPLIT") is not None:   # A/B switch
         model.decoder_split = int(os.environ["CORRIF_DECODER_SPLIT"])
+    if os.environ.get("CORRIF_STREAM_K") is not None:        # A/B switch: 0 = every GEMM as one workgroup per tile
+        ops.STREAM_K = os.environ["CORRIF_STREAM_K"] == "1"
     if os.environ.get("CORRIF_SERIAL") == "1":          # profiling aid: one stream, clean per-kernel attribution
         model.concurrent_branches = False
         model.decoder_fuse.concurrent_skips = False

@@ -33,7 +33,7 @@ class Gemm(C.Structure):
                 ("g", Geom), ("ntap_sel", i32), ("tap_sel", C.c_int8 * 28),
                 ("out_map", i32), ("OD", i32), ("OH", i32), ("OW", i32), ("om_d", i32), ("om_h", i32), ("om_w", i32),
                 ("oo_d", i32), ("oo_h", i32), ("oo_w", i32),
-                ("stats_part", ptr), ("stats_rows_per_group", i64), ("stats_relu", i32)]
+                ("stats_part", ptr), ("stats_rows_per_group", i64), ("stats_relu", i32), ("ws", ptr), ("no_split", i32)]
 
 
 class Wgrad(C.Structure):
@@ -58,6 +58,7 @@ _SIGS = {
     "corrif_abi_version": (i32, []),
     "corrif_build_arch": (C.c_char_p, []),
     "corrif_gemm_fwd": (i32, [C.POINTER(Gemm), ptr]),
+    "corrif_gemm_fwd_workspace": (C.c_size_t, [C.POINTER(Gemm)]),
     "corrif_wgrad": (i32, [C.POINTER(Wgrad), ptr]),
     "corrif_wgrad_workspace": (C.c_size_t, [C.POINTER(Wgrad)]),
     "corrif_wgrad_plan": (i32, [i32, i32, i32]),
@@ -101,6 +102,8 @@ _SIGS = {
     "corrif_gelu_bwd": (i32, [ptr, ptr, ptr, i64, ptr]),
     "corrif_relu_bwd": (i32, [ptr, ptr, ptr, i64, ptr]),
     "corrif_scale_dev": (i32, [ptr, ptr, ptr, i64, ptr]),
+    "corrif_scale": (i32, [ptr, ptr, i64, f32, ptr]),
+    "corrif_fill": (i32, [ptr, i64, f32, ptr]),
     "corrif_copy2d": (i32, [ptr, i64, ptr, i64, i64, i32, i32, ptr]),
     "corrif_sum_groups": (i32, [ptr, ptr, i64, i32, ptr]),
     "corrif_intercorr_fwd": (i32, [ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i32, i32, i32, ptr]),
@@ -134,7 +137,7 @@ def lib():
             fn = getattr(l, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if l.corrif_abi_version() != 2:
+        if l.corrif_abi_version() != 3:
             raise RuntimeError("corrif: ABI version mismatch")
         _lib = l
     return _lib

@@ -15,28 +15,35 @@
 
 // GEMM / BL (= is_gemm / b_layout) are compile-time: one straight-line K loop per variant lets the compiler keep all tile
 // loads in flight together (run-time variants shared basic blocks and forced vmcnt drains at the joins).
+//
+// The kernel body is split in two device functions so that three kernels can share it:
+//   gemm_mainloop : acc += sum over the K tiles [kt0, kt1) of one BM x BN output tile
+//   gemm_epilogue : bias / addend / activation / fused norm statistics / row map, float4 stores through an LDS transpose
+//   gemm_fwd_kernel      one workgroup per output tile (grids that fill the chip many times over)
+//   gemm_sk_kernel       "stream-K": a persistent grid of G = CUs x resident workgroups; workgroup g owns the g-th equal share of
+//                        the (tile, K tile) iteration space, so every CU gets the same number of MFMA iterations whatever the tile
+//                        count (392 tiles of an e4 conv on 512 slots ran at 392/512 = 0.77 occupancy; several shapes of the encoder
+//                        sat at ceil() losses of 15-25 %).  Pieces that cover a whole tile run the normal epilogue; partial pieces
+//                        write their raw accumulators to a slab (at most 2 per workgroup),
+//   gemm_sk_fixup_kernel sums the slabs of every split tile in a FIXED order (ascending workgroup) and runs the same epilogue:
+//                        deterministic, no atomics, no inter-workgroup wait inside a launch.
+template <int BM, int BN, int WM, int WN>
+struct GemmCfg {
+    static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static constexpr int SP = TN * 32 + 4;                       // epilogue staging row pitch (floats)
+};
+
 template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL>
-__global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
+__device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, const float* __restrict__ A, const float* __restrict__ B, float* lds,
+                                              const int m0, const int n0, const int kt0, const int kt1,
+                                              f32x16 (&acc)[BM / WM / 32][BN / WN / 32]) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AI = BM / 32, BI = BN / 32;      // float4 chunks per thread per K tile
-    // one LDS array: [A tile | B tile] during the K loop, re-used as the per-wave output staging area in the epilogue
-    constexpr int SP = TN * 32 + 4;                       // staging row pitch (floats)
     constexpr int PBT = BN + 4;                           // row pitch of the K-major B tile (BL == 1)
-    constexpr int B_FLOATS = BL == 0 ? BN * LDS_PITCH : BK * PBT;
-    constexpr int LDS_FLOATS = BM * LDS_PITCH + B_FLOATS > 4 * 32 * SP ? BM * LDS_PITCH + B_FLOATS : 4 * 32 * SP;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     float* const As = lds;
     float* const Bs = lds + BM * LDS_PITCH;
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const uint32_t tiles_n = (p.N + BN - 1) / BN;
-    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-    const int z = blockIdx.z, zo = z / p.Zi, zi = z - zo * p.Zi;
-    const float* __restrict__ A = p.A + zo * p.sA_o + zi * p.sA_i;
-    const float* __restrict__ B = p.B + zo * p.sB_o + zi * p.sB_i;
-    float* __restrict__ C = p.C + zo * p.sC_o + zi * p.sC_i;
 
     // ---- per-thread staging roles: A chunk column kc (fixed), rows ar + 32*i
     const int kc = tid & 7, ar = tid >> 3;
@@ -60,19 +67,18 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
         }
     }
 
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     f32x4 ra[AI], rb[BI];
-    const int nk = (p.K + BK - 1) / BK;
     int a_off[AI];                        // cached per-row source offsets (floats inside the sample) of tap cur_tap; -1 = zero padding
     uint32_t okA = 0, okB = 0;            // validity bits of ra[] / rb[] (applied at the LDS store)
-    int cur_tap = -1, nx_tap = 0, nx_c4 = kc;   // (tap, float4 chunk) of this thread's chunk in the NEXT tile to load (tiles load in order)
+    // (tap, float4 chunk) of this thread's chunk in the NEXT tile to load (tiles load in order, starting at K tile kt0)
+    int cur_tap = -1, nx_tap = 0, nx_c4 = kc;
+    if constexpr (!GEMM && VEC == 4) {
+        if (kt0 > 0) {
+            const int q0 = kt0 * 8 + kc;
+            nx_tap = q0 / p.Cs4;
+            nx_c4 = q0 - nx_tap * p.Cs4;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < AI; ++i) a_off[i] = -1;
 
@@ -183,11 +189,11 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
     };
 
     const int frow = lane & 31, fk = (lane >> 5) * 4;
-    load_tile(0);
-    for (int kt = 0; kt < nk; ++kt) {
+    load_tile(kt0);
+    for (int kt = kt0; kt < kt1; ++kt) {
         store_tile();
         __syncthreads();
-        if (kt + 1 < nk) load_tile(kt + 1);      // global loads fly while the MFMAs run
+        if (kt + 1 < kt1) load_tile(kt + 1);      // global loads fly while the MFMAs run
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             f32x4 a[TM], b[TN];
@@ -213,118 +219,305 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
         }
         __syncthreads();
     }
+}
 
-    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5): a direct store is 16*TM*TN
-    // scalar store instructions per lane (store-issue bound when K is short).  Instead every wave transposes one 32 x (32*TN)
-    // row block at a time through its private LDS staging area and writes float4 per lane: 4x fewer store instructions and
-    // 128*TN-byte contiguous row segments.  (The last __syncthreads() of the K loop already fenced the A/B tiles.)
-    {
-        constexpr int CQ = TN * 8;                    // float4 chunks per staged row
-        constexpr int RPP = 64 / CQ;                  // rows per pass
-        float* const stg = lds + wave * 32 * SP;
-        const int rr = lane / CQ, cq = lane % CQ;
-        const int col = n0 + wn * TN * 32 + cq * 4;   // this lane's 4 output columns (fixed for all passes)
-        const bool vec_ok = !(p.ldc & 3) && !((uintptr_t)C & 15) && (!p.addend || (!(p.ld_add & 3) && !((uintptr_t)p.addend & 15)));
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
+// ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5): a direct store is 16*TM*TN
+// scalar store instructions per lane (store-issue bound when K is short).  Instead every wave transposes one 32 x (32*TN)
+// row block at a time through its private LDS staging area and writes float4 per lane: 4x fewer store instructions and
+// 128*TN-byte contiguous row segments.  (The caller has fenced the A/B tiles with a __syncthreads() before calling.)
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restrict__ C, float* lds, const int m0, const int n0,
+                                              f32x16 (&acc)[BM / WM / 32][BN / WN / 32]) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int SP = GemmCfg<BM, BN, WM, WN>::SP;
+    constexpr int CQ = TN * 8;                    // float4 chunks per staged row
+    constexpr int RPP = 64 / CQ;                  // rows per pass
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    float* const stg = lds + wave * 32 * SP;
+    const int rr = lane / CQ, cq = lane % CQ;
+    const int col = n0 + wn * TN * 32 + cq * 4;   // this lane's 4 output columns (fixed for all passes)
+    const bool vec_ok = !(p.ldc & 3) && !((uintptr_t)C & 15) && (!p.addend || (!(p.ld_add & 3) && !((uintptr_t)p.addend & 15)));
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (col + e < p.N) bv[e] = p.bias[col + e];
+    }
+    double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};      // fused norm statistics of this lane's 4 columns (double: no cancellation loss)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SP + j * 32 + (lane & 31)] = acc[i][j][r];
+        // same wave wrote and reads: LDS ops of one wave complete in order, no barrier needed
+#pragma unroll
+        for (int ps = 0; ps < 32 / RPP; ++ps) {
+            const int lr = ps * RPP + rr;
+            const int row = m0 + (wm * TM + i) * 32 + lr;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&stg[lr * SP + cq * 4]);
+            if (row >= p.M || col >= p.N) continue;
+            v += bv;
+            if (p.stats_part) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double sv = (double)(p.stats_relu ? fmaxf(v[e], 0.f) : v[e]);
+                    ssum[e] += sv;
+                    ssq[e] += sv * sv;
+                }
+            }
+            int64_t orow = row;
+            if (p.out_map) {       // scatter to the strided sub-grid this GEMM's rows enumerate
+                uint32_t n, pk;
+                decode_row((uint32_t)row, p.g, n, pk);
+                const int od = (int)(pk >> 20) * p.om_d + p.oo_d, oh = (int)((pk >> 10) & 1023) * p.om_h + p.oo_h,
+                          ow = (int)(pk & 1023) * p.om_w + p.oo_w;
+                orow = (((int64_t)n * p.OD + od) * p.OH + oh) * p.OW + ow;
+            }
+            float* __restrict__ dst = C + orow * p.ldc + col;
+            if (vec_ok && col + 3 < p.N) {
+                if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + (int64_t)row * p.ld_add + col);
+                if (p.act == CORRIF_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (p.act == CORRIF_ACT_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                }
+                *reinterpret_cast<f32x4*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (col + e >= p.N) break;
+                    float x = v[e];
+                    if (p.addend) x += p.addend[(int64_t)row * p.ld_add + col + e];
+                    if (p.act == CORRIF_ACT_RELU) x = fmaxf(x, 0.f);
+                    else if (p.act == CORRIF_ACT_GELU) x = gelu_erf(x);
+                    dst[e] = x;
+                }
+            }
+        }
+    }
+    if (p.stats_part) {       // TM == 2: the wave's rows are one 64-row block; sum over the RPP lanes that share a column chunk
+#pragma unroll
+        for (int off = CQ; off < 64; off <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ssum[e] += __shfl_xor(ssum[e], off); ssq[e] += __shfl_xor(ssq[e], off); }
+        const int row0 = m0 + wm * TM * 32;
+        if (lane < CQ && row0 < p.M) {
+            const int g = row0 / p.stats_rpg, chunk = (row0 - g * p.stats_rpg) >> 6;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (col + e < p.N) bv[e] = p.bias[col + e];
-        }
-        double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};      // fused norm statistics of this lane's 4 columns (double: no cancellation loss)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SP + j * 32 + (lane & 31)] = acc[i][j][r];
-            // same wave wrote and reads: LDS ops of one wave complete in order, no barrier needed
-#pragma unroll
-            for (int ps = 0; ps < 32 / RPP; ++ps) {
-                const int lr = ps * RPP + rr;
-                const int row = m0 + (wm * TM + i) * 32 + lr;
-                f32x4 v = *reinterpret_cast<const f32x4*>(&stg[lr * SP + cq * 4]);
-                if (row >= p.M || col >= p.N) continue;
-                v += bv;
-                if (p.stats_part) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const double sv = (double)(p.stats_relu ? fmaxf(v[e], 0.f) : v[e]);
-                        ssum[e] += sv;
-                        ssq[e] += sv * sv;
-                    }
+                if (col + e < p.N) {
+                    double* o = p.stats_part + (((int64_t)g * p.N + col + e) * p.stats_chunks + chunk) * 2;
+                    o[0] = ssum[e];
+                    o[1] = ssq[e];
                 }
-                int64_t orow = row;
-                if (p.out_map) {       // scatter to the strided sub-grid this GEMM's rows enumerate
-                    uint32_t n, pk;
-                    decode_row((uint32_t)row, p.g, n, pk);
-                    const int od = (int)(pk >> 20) * p.om_d + p.oo_d, oh = (int)((pk >> 10) & 1023) * p.om_h + p.oo_h,
-                              ow = (int)(pk & 1023) * p.om_w + p.oo_w;
-                    orow = (((int64_t)n * p.OD + od) * p.OH + oh) * p.OW + ow;
-                }
-                float* __restrict__ dst = C + orow * p.ldc + col;
-                if (vec_ok && col + 3 < p.N) {
-                    if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + (int64_t)row * p.ld_add + col);
-                    if (p.act == CORRIF_ACT_RELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    } else if (p.act == CORRIF_ACT_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                    }
-                    *reinterpret_cast<f32x4*>(dst) = v;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (col + e >= p.N) break;
-                        float x = v[e];
-                        if (p.addend) x += p.addend[(int64_t)row * p.ld_add + col + e];
-                        if (p.act == CORRIF_ACT_RELU) x = fmaxf(x, 0.f);
-                        else if (p.act == CORRIF_ACT_GELU) x = gelu_erf(x);
-                        dst[e] = x;
-                    }
-                }
-            }
-        }
-        if (p.stats_part) {       // TM == 2: the wave's rows are one 64-row block; sum over the RPP lanes that share a column chunk
-#pragma unroll
-            for (int off = CQ; off < 64; off <<= 1)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { ssum[e] += __shfl_xor(ssum[e], off); ssq[e] += __shfl_xor(ssq[e], off); }
-            const int row0 = m0 + wm * TM * 32;
-            if (lane < CQ && row0 < p.M) {
-                const int g = row0 / p.stats_rpg, chunk = (row0 - g * p.stats_rpg) >> 6;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (col + e < p.N) {
-                        double* o = p.stats_part + (((int64_t)g * p.N + col + e) * p.stats_chunks + chunk) * 2;
-                        o[0] = ssum[e];
-                        o[1] = ssq[e];
-                    }
-            }
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN, int VEC = 4>
-static int launch_fwd(const GemmArgs& a, int Z, hipStream_t s) {
-    uint32_t tiles = (uint32_t)((a.M + BM - 1) / BM) * (uint32_t)((a.N + BN - 1) / BN);
-    dim3 grid(tiles, 1, Z);
-    if constexpr (VEC == 1) {
-        hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, 1, false, 0>), grid, dim3(256), 0, s, a);
-    } else if (a.g.is_gemm) {
-        if (a.b_layout == 0) hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC, true, 0>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC, true, 1>), grid, dim3(256), 0, s, a);
-    } else {
-        if (a.b_layout == 0) hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC, false, 0>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC, false, 1>), grid, dim3(256), 0, s, a);
+template <int BM, int BN, int WM, int WN, int BL>
+struct GemmLds {
+    static constexpr int TN = BN / WN / 32;
+    static constexpr int SP = TN * 32 + 4;
+    static constexpr int PBT = BN + 4;
+    static constexpr int B_FLOATS = BL == 0 ? BN * LDS_PITCH : BK * PBT;
+    // one LDS array: [A tile | B tile] during the K loop, re-used as the per-wave output staging area in the epilogue
+    static constexpr int FLOATS = BM * LDS_PITCH + B_FLOATS > 4 * 32 * SP ? BM * LDS_PITCH + B_FLOATS : 4 * 32 * SP;
+};
+
+template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL>
+__global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    __shared__ __attribute__((aligned(16))) float lds[GemmLds<BM, BN, WM, WN, BL>::FLOATS];
+    const uint32_t tiles_n = (p.N + BN - 1) / BN;
+    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int z = blockIdx.z, zo = z / p.Zi, zi = z - zo * p.Zi;
+    const float* __restrict__ A = p.A + zo * p.sA_o + zi * p.sA_i;
+    const float* __restrict__ B = p.B + zo * p.sB_o + zi * p.sB_i;
+    float* __restrict__ C = p.C + zo * p.sC_o + zi * p.sC_i;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    gemm_mainloop<BM, BN, WM, WN, VEC, GEMM, BL>(p, A, B, lds, m0, n0, 0, (p.K + BK - 1) / BK, acc);
+    gemm_epilogue<BM, BN, WM, WN>(p, C, lds, m0, n0, acc);
+}
+
+// unit boundary of stream-K workgroup g: floor(g * U / G)
+__device__ __forceinline__ int64_t sk_bound(int64_t g, int64_t U, int G) { return g * U / G; }
+
+template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL>
+__global__ __launch_bounds__(256) void gemm_sk_kernel(GemmArgs p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    __shared__ __attribute__((aligned(16))) float lds[GemmLds<BM, BN, WM, WN, BL>::FLOATS];
+    const int G = (int)gridDim.x;
+    const int g = (int)xcd_remap(blockIdx.x, gridDim.x);      // neighbouring ranges (shared operand panels) on one XCD's L2
+    const int nk = p.sk_nk;
+    const int64_t U = (int64_t)p.sk_tiles * nk;
+    const int64_t u0 = sk_bound(g, U, G), u1 = sk_bound(g + 1, U, G);
+    const uint32_t tiles_n = (p.N + BN - 1) / BN;
+    const int tid = threadIdx.x;
+    for (int64_t u = u0; u < u1;) {
+        const int t = (int)(u / nk);
+        const int k0 = (int)(u - (int64_t)t * nk);
+        const int k1 = (int)min((int64_t)nk, k0 + (u1 - u));
+        const int z = t / p.sk_tiles_mn, tile = t - z * p.sk_tiles_mn;
+        const int zo = z / p.Zi, zi = z - zo * p.Zi;
+        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+        const float* __restrict__ A = p.A + zo * p.sA_o + zi * p.sA_i;
+        const float* __restrict__ B = p.B + zo * p.sB_o + zi * p.sB_i;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        gemm_mainloop<BM, BN, WM, WN, VEC, GEMM, BL>(p, A, B, lds, m0, n0, k0, k1, acc);
+        if (k0 == 0 && k1 == nk) {
+            gemm_epilogue<BM, BN, WM, WN>(p, p.C + zo * p.sC_o + zi * p.sC_i, lds, m0, n0, acc);
+            __syncthreads();                                  // the staging area is the next piece's A/B tile
+        } else {
+            // partial piece: raw accumulators to this workgroup's slab (0: the piece its range starts with, 1: a later one)
+            float* __restrict__ slab = p.sk_ws + ((int64_t)2 * g + (u == u0 ? 0 : 1)) * (BM * BN);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 4) {
+                        f32x4 v = {acc[i][j][r], acc[i][j][r + 1], acc[i][j][r + 2], acc[i][j][r + 3]};
+                        *reinterpret_cast<f32x4*>(slab + ((((i * TN + j) * 4 + (r >> 2)) * 256 + tid) << 2)) = v;
+                    }
+        }
+        u += k1 - k0;
     }
+}
+
+// one workgroup per interior range boundary g = 1 .. G-1: the workgroup of the FIRST boundary that falls inside a tile owns that tile
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(GemmArgs p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    __shared__ __attribute__((aligned(16))) float lds[4 * 32 * GemmCfg<BM, BN, WM, WN>::SP];
+    const int G = p.sk_G, nk = p.sk_nk;
+    const int g = (int)blockIdx.x + 1;
+    const int64_t U = (int64_t)p.sk_tiles * nk;
+    const int64_t ub = sk_bound(g, U, G);
+    const int t = (int)(ub / nk);
+    const int64_t tb = (int64_t)t * nk, te = tb + nk;
+    if (ub == tb) return;                                     // boundary on a tile edge: nothing is split here
+    if (sk_bound(g - 1, U, G) > tb) return;                   // an earlier boundary already lies inside this tile: its workgroup owns it
+    const int tid = threadIdx.x;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int j2 = g - 1; j2 < G; ++j2) {                       // pieces in ascending workgroup order: a fixed summation order
+        const int64_t b0 = sk_bound(j2, U, G);
+        if (b0 >= te) break;
+        const int which = (b0 >= tb) ? 0 : 1;                 // the piece is the first of workgroup j2's range iff the range starts inside the tile
+        const float* __restrict__ slab = p.sk_ws + ((int64_t)2 * j2 + which) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(slab + ((((i * TN + j) * 4 + (r >> 2)) * 256 + tid) << 2));
+                    acc[i][j][r] += v[0]; acc[i][j][r + 1] += v[1]; acc[i][j][r + 2] += v[2]; acc[i][j][r + 3] += v[3];
+                }
+    }
+    const uint32_t tiles_n = (p.N + BN - 1) / BN;
+    const int z = t / p.sk_tiles_mn, tile = t - z * p.sk_tiles_mn;
+    const int zo = z / p.Zi, zi = z - zo * p.Zi;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    gemm_epilogue<BM, BN, WM, WN>(p, p.C + zo * p.sC_o + zi * p.sC_i, lds, m0, n0, acc);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+// Stream-K plan of one launch: G persistent workgroups (0 = classic one-tile-per-workgroup launch).
+// Classic when the grid already fills the chip many times (ceil() loss < ~6 %) or when there is too little K to split.
+template <typename K>
+static int resident_per_cu(K kernel) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kernel), 256, 0) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        n = 2;
+    }
+    return n > 4 ? 4 : n;
+}
+static int num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); cus = 256; }
+        else cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+static int sk_plan(int64_t tiles_total, int nk, int slots) {
+    if (tiles_total >= 8 * (int64_t)slots) return 0;          // >= 8 full waves: at most 1/8 of a wave is lost to the ceil()
+    const int64_t waves = (tiles_total + slots - 1) / slots;
+    if (tiles_total * 100 >= waves * slots * 92) return 0;    // the one-tile-per-workgroup grid already keeps >= 92 % of the slots busy
+    const int64_t U = tiles_total * nk;
+    int64_t G = slots;
+    if (U < 8 * G) G = U / 8;                                 // at least 8 K tiles of work per workgroup
+    if (G < 2 || (tiles_total <= slots && G <= tiles_total)) return 0;      // too little K to share out: splitting would not add parallelism
+    return (int)G;
+}
+
+template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL>
+static int launch_variant(GemmArgs& a, int Z, hipStream_t s, bool plan_only, size_t* ws_bytes) {
+    static int per_cu = 0;
+    if (!per_cu) per_cu = resident_per_cu(gemm_sk_kernel<BM, BN, WM, WN, VEC, GEMM, BL>);
+    const int64_t tiles_mn = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const int nk = (a.K + BK - 1) / BK;
+    const int G = a.sk_allowed ? sk_plan(tiles_mn * Z, nk, num_cus() * per_cu) : 0;
+    if (ws_bytes) *ws_bytes = G ? (size_t)2 * G * BM * BN * sizeof(float) : 0;
+    if (plan_only) return CORRIF_OK;
+    if (G && !a.sk_ws) return CORRIF_EINVAL;                  // the caller did not provide the workspace corrif_gemm_fwd_workspace asked for
+    if (!G) {
+        dim3 grid((uint32_t)tiles_mn, 1, Z);
+        hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC, GEMM, BL>), grid, dim3(256), 0, s, a);
+        CORRIF_CHECK_LAUNCH();
+        return CORRIF_OK;
+    }
+    a.sk_G = G; a.sk_nk = nk; a.sk_tiles_mn = (int)tiles_mn; a.sk_tiles = (int)(tiles_mn * Z);
+    hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, WM, WN, VEC, GEMM, BL>), dim3(G), dim3(256), 0, s, a);
+    CORRIF_CHECK_LAUNCH();
+    hipLaunchKernelGGL((gemm_sk_fixup_kernel<BM, BN, WM, WN>), dim3(G - 1), dim3(256), 0, s, a);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
 
-extern "C" int corrif_gemm_fwd(const CorrifGemm* p, void* stream) {
+template <int BM, int BN, int WM, int WN, int VEC = 4>
+static int launch_fwd(GemmArgs& a, int Z, hipStream_t s, bool plan_only, size_t* ws_bytes) {
+    if constexpr (VEC == 1) {
+        return launch_variant<BM, BN, WM, WN, 1, false, 0>(a, Z, s, plan_only, ws_bytes);
+    } else if (a.g.is_gemm) {
+        if (a.b_layout == 0) return launch_variant<BM, BN, WM, WN, VEC, true, 0>(a, Z, s, plan_only, ws_bytes);
+        return launch_variant<BM, BN, WM, WN, VEC, true, 1>(a, Z, s, plan_only, ws_bytes);
+    } else {
+        if (a.b_layout == 0) return launch_variant<BM, BN, WM, WN, VEC, false, 0>(a, Z, s, plan_only, ws_bytes);
+        return launch_variant<BM, BN, WM, WN, VEC, false, 1>(a, Z, s, plan_only, ws_bytes);
+    }
+}
+
+// validation + tile choice + launch (plan_only: only report the stream-K workspace the launch would need)
+static int gemm_fwd_impl(const CorrifGemm* p, void* stream, bool plan_only, size_t* ws_bytes) {
+    if (ws_bytes) *ws_bytes = 0;
     if (!p || !p->A || !p->B || !p->C) return CORRIF_EINVAL;
     if (p->M <= 0 || p->N <= 0 || p->K <= 0 || p->Z < 1 || p->Zi < 1) return CORRIF_EINVAL;
     const bool scalar = p->Cs == 1;
@@ -344,6 +537,7 @@ extern "C" int corrif_gemm_fwd(const CorrifGemm* p, void* stream) {
     if (!p->g.is_gemm && !scalar && p->K != (p->ntap_sel ? p->ntap_sel : p->g.kd * p->g.kh * p->g.kw) * p->Cs) return CORRIF_EINVAL;
     if (scalar && (p->g.ntaps <= 0 || p->g.ntaps > p->g.kd * p->g.kh * p->g.kw || p->K < p->g.ntaps)) return CORRIF_EINVAL;
     if (p->Z > 65535) return CORRIF_EUNSUPPORTED;
+    if (p->ws && ((uintptr_t)p->ws & 15)) return CORRIF_EUNSUPPORTED;
     GemmArgs a;
     a.A = p->A; a.B = p->B; a.C = p->C; a.bias = p->bias; a.addend = p->addend;
     a.lda = p->lda; a.ldb = p->ldb; a.ldc = p->ldc; a.ld_add = p->ld_add;
@@ -362,28 +556,44 @@ extern "C" int corrif_gemm_fwd(const CorrifGemm* p, void* stream) {
     }
     a.out_map = p->out_map; a.OD = p->OD; a.OH = p->OH; a.OW = p->OW;
     a.om_d = p->om_d; a.om_h = p->om_h; a.om_w = p->om_w; a.oo_d = p->oo_d; a.oo_h = p->oo_h; a.oo_w = p->oo_w;
+    a.sk_ws = p->ws; a.sk_G = 0; a.sk_nk = 0; a.sk_tiles = 0; a.sk_tiles_mn = 0;
+    a.sk_allowed = p->no_split ? 0 : 1;
     hipStream_t s = (hipStream_t)stream;
-    if (scalar) return launch_fwd<128, 64, 2, 2, 1>(a, p->Z, s);
+    const int Z = p->Z;
+    if (scalar) return launch_fwd<128, 64, 2, 2, 1>(a, Z, s, plan_only, ws_bytes);
     if (p->ntap_sel || p->out_map) {       // parity-class data gradient: only the 32x32-MFMA tiles implement these options
-        if (p->N <= 32) return launch_fwd<256, 32, 4, 1>(a, p->Z, s);
-        if (p->N <= 64) return launch_fwd<128, 64, 2, 2>(a, p->Z, s);
-        return launch_fwd<128, 128, 2, 2>(a, p->Z, s);
+        if (p->N <= 32) return launch_fwd<256, 32, 4, 1>(a, Z, s, plan_only, ws_bytes);
+        if (p->N <= 64) return launch_fwd<128, 64, 2, 2>(a, Z, s, plan_only, ws_bytes);
+        return launch_fwd<128, 128, 2, 2>(a, Z, s, plan_only, ws_bytes);
     }
     if (p->N <= 16 && !(p->N & 3) && !(p->ldc & 3) && !((uintptr_t)p->C & 15) && !(p->sC_o & 3) && !(p->sC_i & 3) &&
-        (!p->addend || (!(p->ld_add & 3) && !((uintptr_t)p->addend & 15))))
-        return launch_smalln_fwd(a, p->Z, s);
-    if (p->N <= 32) return launch_fwd<256, 32, 4, 1>(a, p->Z, s);
-    // 128-wide tiles measured faster than 64x64 even at ~1.5 workgroups per CU (e4: M=25088,N=256,K=2304: 70 vs 56 TF/s);
-    // shrink only when the grid could not even cover the 256 CUs once.
-    auto tiles = [&](int bm, int bn) { return (int64_t)((p->M + bm - 1) / bm) * ((p->N + bn - 1) / bn) * p->Z; };
-    const bool st = p->stats_part != nullptr;       // fused statistics need 64-row wave blocks (TM = 2)
-    if (p->N <= 64) {
-        if (st || tiles(128, 64) >= 192) return launch_fwd<128, 64, 2, 2>(a, p->Z, s);
-        return launch_fwd<64, 64, 2, 2>(a, p->Z, s);
+        (!p->addend || (!(p->ld_add & 3) && !((uintptr_t)p->addend & 15)))) {
+        if (plan_only) return CORRIF_OK;
+        return launch_smalln_fwd(a, Z, s);
     }
-    if (tiles(128, 128) >= 192) return launch_fwd<128, 128, 2, 2>(a, p->Z, s);
-    if (st || tiles(128, 64) >= 192) return launch_fwd<128, 64, 2, 2>(a, p->Z, s);
-    return launch_fwd<64, 64, 2, 2>(a, p->Z, s);
+    if (p->N <= 32) return launch_fwd<256, 32, 4, 1>(a, Z, s, plan_only, ws_bytes);
+    // 128-wide tiles measured faster than 64x64 even at ~1.5 workgroups per CU (e4: M=25088,N=256,K=2304: 70 vs 56 TF/s);
+    // shrink only when the grid could not even cover the 256 CUs once.  (With the stream-K split the tile count no longer has to
+    // cover the chip: the K loop is what is shared out.)
+    auto tiles = [&](int bm, int bn) { return (int64_t)((p->M + bm - 1) / bm) * ((p->N + bn - 1) / bn) * p->Z; };
+    const int nk = (p->K + BK - 1) / BK;
+    const bool st = p->stats_part != nullptr;       // fused statistics need 64-row wave blocks (TM = 2)
+    const bool splittable = a.sk_allowed != 0;
+    if (p->N <= 64) {
+        if (st || tiles(128, 64) >= 192 || (splittable && tiles(128, 64) * nk >= 2048)) return launch_fwd<128, 64, 2, 2>(a, Z, s, plan_only, ws_bytes);
+        return launch_fwd<64, 64, 2, 2>(a, Z, s, plan_only, ws_bytes);
+    }
+    if (tiles(128, 128) >= 192 || (splittable && tiles(128, 128) * nk >= 2048)) return launch_fwd<128, 128, 2, 2>(a, Z, s, plan_only, ws_bytes);
+    if (st || tiles(128, 64) >= 192) return launch_fwd<128, 64, 2, 2>(a, Z, s, plan_only, ws_bytes);
+    return launch_fwd<64, 64, 2, 2>(a, Z, s, plan_only, ws_bytes);
+}
+
+extern "C" int corrif_gemm_fwd(const CorrifGemm* p, void* stream) { return gemm_fwd_impl(p, stream, false, nullptr); }
+
+extern "C" size_t corrif_gemm_fwd_workspace(const CorrifGemm* p) {
+    size_t n = 0;
+    if (gemm_fwd_impl(p, nullptr, true, &n) != CORRIF_OK) return 0;
+    return n;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -14,6 +14,9 @@ struct GemmArgs {
     int ntap_sel; int8_t tap_sel[28];
     int out_map, OD, OH, OW, om_d, om_h, om_w, oo_d, oo_h, oo_w;
     double* stats_part; int stats_relu; int stats_rpg, stats_chunks;
+    // stream-K split (igemm.hip): G persistent workgroups share sk_tiles * sk_nk (tile, K tile) iterations; partial accumulators go to
+    // sk_ws[2 * G][BM * BN]; sk_tiles = sk_tiles_mn * Z
+    float* sk_ws; int sk_G, sk_nk, sk_tiles, sk_tiles_mn, sk_allowed;
 };
 
 

@@ -103,6 +103,33 @@ extern "C" int corrif_scale_dev(const float* x, const float* scalar, float* y, i
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
+__global__ void scale_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float alpha) {
+    GRID_STRIDE(i, n) y[i] = x[i] * alpha;
+}
+__global__ void scale4_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n4, float alpha) {
+    GRID_STRIDE(i, n4) reinterpret_cast<f32x4*>(y)[i] = reinterpret_cast<const f32x4*>(x)[i] * alpha;
+}
+extern "C" int corrif_scale(const float* x, float* y, int64_t n, float alpha, void* stream) {
+    if (!x || !y || n <= 0) return CORRIF_EINVAL;
+    if (!(n & 3) && al16(x) && al16(y)) hipLaunchKernelGGL(scale4_kernel, dim3(nblocks(n / 4)), dim3(256), 0, (hipStream_t)stream, x, y, n / 4, alpha);
+    else hipLaunchKernelGGL(scale_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, alpha);
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}
+__global__ void fill_kernel(float* __restrict__ y, int64_t n, float v) {
+    GRID_STRIDE(i, n) y[i] = v;
+}
+__global__ void fill4_kernel(float* __restrict__ y, int64_t n4, float v) {
+    const f32x4 v4 = {v, v, v, v};
+    GRID_STRIDE(i, n4) reinterpret_cast<f32x4*>(y)[i] = v4;
+}
+extern "C" int corrif_fill(float* y, int64_t n, float value, void* stream) {
+    if (!y || n <= 0) return CORRIF_EINVAL;
+    if (!(n & 3) && al16(y)) hipLaunchKernelGGL(fill4_kernel, dim3(nblocks(n / 4)), dim3(256), 0, (hipStream_t)stream, y, n / 4, value);
+    else hipLaunchKernelGGL(fill_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, y, n, value);
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}
 __global__ void copy2d_kernel(const float* __restrict__ src, int64_t lds, float* __restrict__ dst, int64_t ldd, int64_t rows, int C4,
                               int acc) {
     int64_t total = rows * C4;

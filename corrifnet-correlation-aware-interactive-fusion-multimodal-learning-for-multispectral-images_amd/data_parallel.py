@@ -7,36 +7,65 @@ gradients are averaged across ranks.
 
 Design for xGMI (point-to-point links, ring collectives are per-link bound): few large buckets (default 64 MB) issued in
 reverse-forward order from autograd post-accumulate hooks on a side stream, so the all-reduce of the decoder's gradients
-overlaps the encoders' backward; the 18 parameters that never receive a gradient are never communicated; gradients live
-as views of the flat buckets so no flatten/unflatten copies are made.
+overlaps the encoders' backward; the parameters that never receive a gradient (the model names them: `NOGRAD_PREFIXES`,
+18 tensors for MMVit4) are never communicated; gradients live as views of the flat buckets so no flatten/unflatten copies
+are made.  Buckets exist before the first backward (the grad-less set is known from the model), so step 1 overlaps like
+every other step; collectives are issued strictly in bucket-index order on every rank (a bucket that completes early waits
+for its predecessors), so the order never depends on the autograd engine's scheduling; the 1/world averaging runs on the
+communication stream right behind each all-reduce (own kernel, no ATen launch).
+
+BatchNorm buffers (running statistics, counters) stay per rank during training; `sync_buffers` / `save_checkpoint`
+implement the SURVEY section 8(e) policy: rank 0's buffers are broadcast before a checkpoint is written, and rank 0 writes it.
 """
 import torch
 import torch.distributed as dist
 
 
+def _scale_(flat, alpha):
+    if flat.is_cuda:
+        import corrif_hip as H
+        H.check(H.lib().corrif_scale(flat.data_ptr(), flat.data_ptr(), flat.numel(), alpha, H.stream()), "corrif_scale")
+    else:                                  # gloo rehearsal on CPU tensors (tests): host arithmetic
+        flat.mul_(alpha)
+
+
+def _zero_(flat):
+    if flat.is_cuda:
+        import corrif_hip as H
+        H.check(H.lib().corrif_fill(flat.data_ptr(), flat.numel(), 0.0, H.stream()), "corrif_fill")
+    else:
+        flat.zero_()
+
+
 class GradAllReducer:
-    def __init__(self, model, bucket_bytes=64 << 20, process_group=None, overlap=True, force_collective=False):
+    def __init__(self, model, bucket_bytes=64 << 20, process_group=None, overlap=True, force_collective=False, skip_prefixes=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.force = force_collective and dist.is_initialized()      # run the collectives even with one rank (single-GPU rehearsal)
+        self.active = self.world > 1 or self.force
         self.overlap = overlap
         self._limit = max(1, bucket_bytes // 4)
-        self.params = [p for p in model.parameters() if p.requires_grad]
-        self.buckets = None          # built lazily after the first backward (only then is the grad-less set known)
-        self._pending = []
+        if skip_prefixes is None:
+            skip_prefixes = getattr(model, "NOGRAD_PREFIXES", None)
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        self.params = [p for _, p in named]
+        self.buckets = None
         self._hooks = []
         self._stream = None
+        self._next = 0
+        if skip_prefixes is not None:        # the grad-less set is known: buckets (and hooks) exist before the first backward
+            self._build([p for n, p in named if not n.startswith(tuple(skip_prefixes))])
+        # else: built lazily after the first backward, from the parameters that did receive a gradient
 
     # ---------------------------------------------------------------- bucket construction
-    def _build(self):
-        live = [p for p in self.params if p.grad is not None]
+    def _build(self, live):
+        live = list(live)
         live.reverse()               # reverse registration order ~ order in which backward produces them
         self.buckets, cur, size = [], [], 0
-        limit = self._bucket_elems()
         for p in live:
             cur.append(p)
             size += p.numel()
-            if size >= limit:
+            if size >= self._limit:
                 self.buckets.append(self._make_bucket(cur))
                 cur, size = [], 0
         if cur:
@@ -45,43 +74,49 @@ class GradAllReducer:
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
                 self._index[p] = bi
-        if self.overlap and live and live[0].is_cuda:
+        if self.active and self.overlap and live and live[0].is_cuda:
             self._stream = torch.cuda.Stream()
             for p in live:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
-    def _bucket_elems(self):
-        return self._limit
-
     def _make_bucket(self, params):
         n = sum(p.numel() for p in params)
         flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
-        views, o = [], 0
+        o = 0
         for p in params:
             v = flat[o:o + p.numel()].view_as(p)
-            v.copy_(p.grad)
+            if p.grad is not None:
+                v.copy_(p.grad)
             p.grad = v               # gradient now lives inside the bucket (autograd accumulates in place)
-            views.append(v)
             o += p.numel()
-        return {"params": params, "flat": flat, "ready": 0, "work": None, "events": []}
+        return {"params": params, "flat": flat, "ready": 0, "work": None, "events": [], "launched": False}
 
     # ---------------------------------------------------------------- hooks / reduction
     def _on_grad(self, p):
+        """post-accumulate hook (only installed when collectives will run): count the bucket's parameters; remember on which
+        stream each gradient was produced (the model runs its modality branches / sample-group lanes on several streams)"""
         b = self.buckets[self._index[p]]
         b["ready"] += 1
-        if self._stream is not None:
-            # gradients of one bucket may be accumulated on different streams (the model runs its three modality branches
-            # on three streams): remember where each one was produced
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            b["events"].append(ev)
-        if b["ready"] == len(b["params"]):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        b["events"].append(ev)
+        self._launch_ready()
+
+    def _launch_ready(self):
+        """issue every complete bucket whose predecessors have all been issued: strict index order on every rank"""
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            if b["ready"] < len(b["params"]):
+                return
             self._launch(b)
+            self._next += 1
 
     def _launch(self, b):
-        if self.world == 1 and not self.force:
+        b["launched"] = True
+        if not self.active:
             b["events"] = []
             return
+        alpha = 1.0 / self.world
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())
             for ev in b["events"]:
@@ -89,6 +124,10 @@ class GradAllReducer:
             b["events"] = []
             with torch.cuda.stream(self._stream):
                 b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.world > 1:
+                    b["work"].wait()             # stream-level dependency only (does not block the host for RCCL)
+                    _scale_(b["flat"], alpha)    # average on the communication stream, behind the collective
+                    b["scaled"] = True
         else:
             b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
@@ -99,29 +138,35 @@ class GradAllReducer:
                 p.grad = None
             return
         for b in self.buckets:
-            b["flat"].zero_()
+            _zero_(b["flat"])
             b["ready"] = 0
             b["work"] = None
             b["events"] = []
+            b["launched"] = False
+            b["scaled"] = False
+        self._next = 0
 
     def finish(self):
-        """call after backward(): waits for / issues the all-reduces and averages.  After it returns every rank holds the
-        mean gradient in p.grad."""
-        first = self.buckets is None
-        if first:
-            self._build()
-        for b in self.buckets:
-            if (self.world > 1 or self.force) and (b["work"] is None):
-                self._launch(b)      # first step (hooks not yet installed) or overlap disabled
+        """call after backward(): issues whatever the hooks have not issued (in index order), waits, averages.  After it returns
+        every rank holds the mean gradient in p.grad."""
+        if self.buckets is None:
+            self._build([p for p in self.params if p.grad is not None])
+        if not self.active:
+            return
+        for b in self.buckets:           # first lazy step / overlap disabled / a bucket whose hooks did not all fire
+            if not b["launched"]:
+                self._launch(b)
+        self._next = len(self.buckets)
         for b in self.buckets:
             if b["work"] is not None:
                 b["work"].wait()
                 b["work"] = None
-            if self.world > 1 or self.force:
-                if self._stream is not None:
-                    torch.cuda.current_stream().wait_stream(self._stream)
-                b["flat"].mul_(1.0 / self.world)
+            if self.world > 1 and not b.get("scaled"):
+                _scale_(b["flat"], 1.0 / self.world)
+                b["scaled"] = True
             b["ready"] = 0
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
 
     def communicated_elements(self):
         return 0 if self.buckets is None else sum(b["flat"].numel() for b in self.buckets)
@@ -133,6 +178,26 @@ def broadcast_module_state(model, src=0, group=None):
         return
     for t in list(model.parameters()) + list(model.buffers()):
         dist.broadcast(t.data, src, group=group)
+
+
+def sync_buffers(model, src=0, group=None):
+    """SURVEY section 8(e) buffer policy: BatchNorm running statistics / counters are per rank during training (as under
+    DistributedDataParallel with broadcast_buffers=False); before a checkpoint is taken every rank adopts rank `src`'s buffers"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in model.buffers():            # MMVit4.buffers() brings the host-side BatchNorm counters up to date first
+        dist.broadcast(t.data, src, group=group)
+
+
+def save_checkpoint(model, path, src=0, group=None):
+    """`torch.save(model.state_dict(), path)` (F4_TRAIN.py:84,86) for a data-parallel job: buffers synchronised from rank `src`,
+    written by rank `src` only, every rank returns after the file exists"""
+    sync_buffers(model, src, group)
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if rank == src:
+        torch.save(model.state_dict(), path)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.barrier(group=group)
 
 
 def shard_batch(x, rank, world):

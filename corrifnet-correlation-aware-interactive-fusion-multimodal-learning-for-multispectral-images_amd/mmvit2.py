@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 import ops
-from mmvit4 import (_rs, _run_lanes, Conv3dP, Decoder_fuse, Transformer, _MODS, basic_dims, depth, general_conv3d_prenorm, mlp_dim, num_heads,
+from mmvit4 import (_Edges, _rs, _run_lanes, Conv3dP, Decoder_fuse, Transformer, _MODS, basic_dims, depth, general_conv3d_prenorm, mlp_dim, num_heads,
                     num_modals, patch_size, transformer_basic_dims)
 
 
@@ -50,6 +50,9 @@ class Encoder(nn.Module):
 
 
 class MMVit2(nn.Module):
+    NOGRAD_PREFIXES = ("RGB_decode_conv.", "NIR_decode_conv.", "SWIR_decode_conv.", "decoder_fuse.seg_d1.", "decoder_fuse.seg_d2.",
+                       "decoder_fuse.seg_d3.", "decoder_fuse.seg_d4.", "decoder_fuse.seg_layer.")      # never called (mmmvit2.py)
+
     def __init__(self, num_cls=1):
         super().__init__()
         d8, T = basic_dims * 8, transformer_basic_dims
@@ -69,12 +72,14 @@ class MMVit2(nn.Module):
         self.decoder_split = 2          # sample-group lanes from the multimodal transformer on (see mmvit4._run_lanes)
         self._streams = None
         self._dec_streams = None
+        self._edges = _Edges()
 
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("mmvit2.MMVit2 runs on the MI355X kernels only: move the model and the input to a HIP device")
         B, T, P3 = x.shape[0], transformer_basic_dims, patch_size
         x = x.contiguous()
+        self._edges.reset()
         feats, qkv = [None] * 3, [None] * 3
 
         def branch(i, m):
@@ -89,12 +94,12 @@ class MMVit2(nn.Module):
                 self._streams = [torch.cuda.Stream(device=x.device) for _ in range(num_modals)]
             for i, m in enumerate(_MODS):
                 st = self._streams[i]
-                st.wait_stream(cur)
+                self._edges.edge(cur, st)
                 _rs(x, st)
                 with torch.cuda.stream(st):
                     branch(i, m)
             for st in self._streams:
-                cur.wait_stream(st)
+                self._edges.edge(st, cur)
             for i in range(num_modals):
                 for t in feats[i] + [qkv[i]]:
                     _rs(t, cur)

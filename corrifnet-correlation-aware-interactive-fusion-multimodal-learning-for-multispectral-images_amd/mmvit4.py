@@ -37,6 +37,39 @@ def _rs(t, stream):
         t.record_stream(stream)
 
 
+class _Edges:
+    """Fork / join edges between the model's HIP streams, built on PERSISTENT events.
+
+    `a.wait_stream(b)` (and a `torch.cuda.Event()` local) creates an event, records it and destroys it again a few lines later.
+    In eager mode that is harmless.  While a HIP graph is being captured it is what made the process crash "on the next eager
+    forward or capture" in round 1: an event recorded on a capturing stream is entered into that stream's list of captured events,
+    `hipStreamEndCapture` walks that list to take every event out of capture mode, and an event that was destroyed in between is a
+    dangling pointer there (heap corruption: the fault shows up later, wherever the freed block is reused - which is why it was
+    seen after a capture that itself replayed bit-identically, and why the single-stream capture, which records no event, never
+    showed it).  So: every edge uses an event from a pool owned by the module, created once, never destroyed while the module is
+    alive.  `reset()` rewinds the pool at the start of a forward; re-recording an event is safe because a wait that was already
+    enqueued refers to the record that preceded it (hipStreamWaitEvent snapshots the event at the call)."""
+
+    def __init__(self):
+        self.events, self.i = [], 0
+
+    def reset(self):
+        self.i = 0
+
+    def mark(self, src):
+        """a pooled event recorded on `src` now (wait for it later with stream.wait_event)"""
+        if self.i == len(self.events):
+            self.events.append(torch.cuda.Event())
+        ev = self.events[self.i]
+        self.i += 1
+        ev.record(src)
+        return ev
+
+    def edge(self, src, dst):
+        """everything enqueued on `src` so far happens before whatever is enqueued on `dst` from here on"""
+        dst.wait_event(self.mark(src))
+
+
 def _triple(v):
     return (v, v, v) if isinstance(v, int) else tuple(v)
 
@@ -65,6 +98,11 @@ class Conv3dP(nn.Module):
 
 
 class BatchNorm3dP(nn.Module):
+    """nn.BatchNorm3d parameters / buffers (mmvit4.py:121,130-151).  `num_batches_tracked` is bookkeeping only (momentum is fixed at
+    0.1, so nothing reads it): training forwards count on the host (`_nbt_pending`) and the int64 buffer is brought up to date
+    whenever it is looked at - attribute access, `state_dict()`, `MMVit4.buffers()` - instead of costing one device launch per
+    BatchNorm layer and step (159 `add` launches per step in round 1)."""
+
     def __init__(self, c, eps=1e-5, momentum=0.1):
         super().__init__()
         self.eps, self.momentum = eps, momentum
@@ -73,10 +111,26 @@ class BatchNorm3dP(nn.Module):
         self.register_buffer("running_mean", torch.zeros(c))
         self.register_buffer("running_var", torch.ones(c))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self._nbt_pending = 0
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_counter())
+
+    def flush_counter(self):
+        if self._nbt_pending:
+            n, self._nbt_pending = self._nbt_pending, 0
+            self._buffers["num_batches_tracked"] += n
+
+    def __getattr__(self, name):
+        if name == "num_batches_tracked":
+            self.flush_counter()
+        return super().__getattr__(name)
+
+    def _load_from_state_dict(self, *a, **kw):
+        self._nbt_pending = 0                      # the loaded counter replaces whatever was pending
+        return super()._load_from_state_dict(*a, **kw)
 
     def forward(self, x, residual=None, relu_in=False, relu_out=False, out=None, pre=None):
         if self.training:
-            self.num_batches_tracked += 1
+            self._nbt_pending += 1
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, residual, relu_in, relu_out,
                               self.training, self.momentum, self.eps, out, pre)
 
@@ -251,6 +305,7 @@ class Decoder_fuse(nn.Module):
         self.final_conv = Conv3dP(8, 3, 1)
         self.concurrent_skips = True
         self._side = None
+        self._edges = {}
 
     def forward(self, x1, x2, x3, x4, x5, lane=0):
         B, dev = x5.shape[0], x5.device
@@ -271,7 +326,9 @@ class Decoder_fuse(nn.Module):
             cur = torch.cuda.current_stream()
             if side is None:
                 side = self._side[lane] = torch.cuda.Stream(device=dev)
-            side.wait_stream(cur)
+            edges = self._edges.setdefault(lane, _Edges())
+            edges.reset()
+            edges.edge(cur, side)
             for t in (x1, x2, x3, x4) + tuple(cats):      # allocated on the caller's stream, used (and saved) on the side stream
                 _rs(t, side)
             events = []
@@ -279,9 +336,7 @@ class Decoder_fuse(nn.Module):
                 for l, (rfm, skip, n, _, _, _) in enumerate(stages):
                     cs = skip.shape[-1]
                     parts_s[l] = ops.nearest(rfm(skip), (n, n, n), out=cats[l][..., :cs])     # F.interpolate nearest (mmvit4.py:271-286)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    events.append(ev)
+                    events.append(edges.mark(side))
         y = self.RFM5(x5)
         if self.RFM5_reduce is not None:
             y = self.RFM5_reduce(y)
@@ -390,6 +445,12 @@ class Transformer(nn.Module):
 
 
 class MMVit4(nn.Module):
+    # parameters that never receive a gradient: the *_decode_conv and seg_* heads are never called and fusion5's
+    # output is never consumed (mmvit4.py:453 vs :532).  torch.optim.Adam skips them (grad is None); the data-parallel layer reads
+    # this list so that they are never communicated and its buckets exist before the first backward.
+    NOGRAD_PREFIXES = ("RGB_decode_conv.", "NIR_decode_conv.", "SWIR_decode_conv.", "decoder_fuse.seg_d1.", "decoder_fuse.seg_d2.",
+                       "decoder_fuse.seg_d3.", "decoder_fuse.seg_d4.", "decoder_fuse.seg_layer.", "fusion5.conv.")
+
     def __init__(self, num_cls=1):
         super().__init__()
         d8, T = basic_dims * 8, transformer_basic_dims
@@ -418,7 +479,18 @@ class MMVit4(nn.Module):
         # of the other.  Forward values are unchanged; decoder weight gradients become the sum of two half-batch reductions.
         self.decoder_split = 2          # number of sample groups (0 / 1 = off)
         self._dec_streams = None
+        self._edges = _Edges()
         self.auto_streams = True        # single-stream schedule when the step's autograd state nears the HBM capacity
+
+    def flush_counters(self):
+        """bring every BatchNorm's `num_batches_tracked` buffer up to date (see BatchNorm3dP)"""
+        for m in self.modules():
+            if isinstance(m, BatchNorm3dP):
+                m.flush_counter()
+
+    def named_buffers(self, *a, **kw):
+        self.flush_counters()
+        return super().named_buffers(*a, **kw)
 
     @staticmethod
     def _level_shapes(B, D, H, W):
@@ -454,6 +526,7 @@ class MMVit4(nn.Module):
     def _forward(self, x):
         B = x.shape[0]
         P3, T = patch_size, transformer_basic_dims
+        self._edges.reset()
         # early-fusion concat buffers, allocated up front on the caller's stream (the branches fill their channel slices)
         cats = [torch.empty(sh + (num_modals * c,), dtype=torch.float32, device=x.device)
                 for sh, (_, c) in zip(self._level_shapes(B, x.shape[2], x.shape[3], x.shape[4]), _ADAPT)]
@@ -473,7 +546,7 @@ class MMVit4(nn.Module):
                 self._streams = [torch.cuda.Stream(device=x.device) for _ in range(num_modals)]
             for i, m in enumerate(_MODS):
                 st = self._streams[i]
-                st.wait_stream(cur)
+                self._edges.edge(cur, st)
                 # tensors allocated on the caller's stream that this branch reads / writes (also from its saved-for-backward
                 # state): tell the caching allocator, or their memory could be re-used while the branch stream still needs it
                 _rs(x, st)
@@ -482,7 +555,7 @@ class MMVit4(nn.Module):
                 with torch.cuda.stream(st):
                     branch(i, m)
             for st in self._streams:
-                cur.wait_stream(st)
+                self._edges.edge(st, cur)
             for i in range(num_modals):        # branch outputs are consumed on the caller's stream from here on
                 for t in feats[i] + [skip[i], qkv[i]]:
                     _rs(t, cur)
@@ -532,14 +605,14 @@ def _run_lanes(model, tail, shared, *per_sample):
     outs = []
     for k in range(lanes):
         st = model._dec_streams[k]
-        st.wait_stream(cur)
+        model._edges.edge(cur, st)
         _rs(shared, st)
         for t in ins:
             _rs(t[k], st)
         with torch.cuda.stream(st):
             outs.append(tail(*[t[k] for t in ins], lane=k))
     for k in range(lanes):
-        cur.wait_stream(model._dec_streams[k])
+        model._edges.edge(model._dec_streams[k], cur)
         _rs(outs[k], cur)
     return ops.cat_batch(*outs)
 

@@ -54,6 +54,9 @@ def _ws(nbytes, dev):
     return H.ws_bytes(nbytes, dev)
 
 
+STREAM_K = True       # diagnostics / A-B: False launches every GEMM as one workgroup per tile
+
+
 def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, addend=None, ld_add=0, act=ACT_NONE,
          Z=1, Zi=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), taps=None, out_map=None, stats=None):
     g = H.Gemm()
@@ -78,6 +81,12 @@ def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, add
     g.sB_o, g.sB_i = sB
     g.sC_o, g.sC_i = sC
     g.g = geom
+    g.no_split = 0 if STREAM_K else 1
+    buf = None
+    nws = lib().corrif_gemm_fwd_workspace(g)          # stream-K split: slabs for the tiles a share boundary cuts
+    if nws:
+        buf = _ws(nws, torch.device("cuda", torch.cuda.current_device()))
+        g.ws = buf.data_ptr()
     check(lib().corrif_gemm_fwd(g, stream()), "corrif_gemm_fwd")
 
 
@@ -613,20 +622,40 @@ gelu = GeluFn.apply
 
 
 class _Philox:
-    """Counter-based dropout stream: (seed, running offset).  Re-seeded from torch's default generator on demand."""
-    seed = 0x5EED
+    """Counter-based dropout stream: (seed, running offset).
+
+    The seed follows torch's default generator: whenever `torch.initial_seed()` differs from the value seen at the previous
+    reservation (`torch.manual_seed(...)` was called, as F2_MAIN-style scripts do for reproducibility), the stream is re-keyed
+    from it and the offset restarts at 0; `rank_offset` (set by the data-parallel layer) decorrelates the ranks of one job.
+    `ops.manual_seed(s)` pins an explicit seed instead (bench.py, tests)."""
+    seed = None             # None: follow torch.initial_seed()
     offset = 0
+    rank_offset = 0
+    _torch_seed = None
 
     @classmethod
     def reserve(cls, n):
+        if cls.seed is None or cls._torch_seed is not None:
+            ts = torch.initial_seed()
+            if ts != cls._torch_seed:
+                cls._torch_seed = ts
+                cls.seed = (ts * 0x9E3779B97F4A7C15 + 0x5EED + cls.rank_offset * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+                cls.offset = 0
         off = cls.offset
         cls.offset += (n + 3) // 4 * 4
         return cls.seed, off
 
 
 def manual_seed(seed):
+    """explicit dropout seed (detaches the stream from torch's generator until `follow_torch_seed()`)"""
     _Philox.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    _Philox._torch_seed = None
     _Philox.offset = 0
+
+
+def follow_torch_seed(rank=0):
+    """derive the dropout stream from torch.initial_seed() (+ the data-parallel rank) again"""
+    _Philox.seed, _Philox._torch_seed, _Philox.rank_offset, _Philox.offset = None, None, int(rank), 0
 
 
 class DropoutFn(Function):

@@ -26,30 +26,49 @@ class FusedAdam:
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.state = {}
         self.t = 0
-        self._sig = None
+        self._sig = self._ptr_sig = None
 
     def zero_grad(self):
         for p in self.params:
             p.grad = None
 
     def _tables(self, live):
-        sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p in live)
-        if sig == self._sig:
-            return
+        """Device tables of the one-launch update.  The block lists (which 1024-element block belongs to which tensor) depend on the
+        SET of live parameters only and are built once; the 40-byte pointer records are refreshed whenever a gradient lives at a new
+        address (`zero_grad()` drops the gradients like torch.optim's set_to_none, so the allocator may hand out other blocks next
+        step): 1122 records = 45 kB through a pinned staging buffer, instead of re-building an 83k-entry block table per step."""
         dev = live[0].device
-        raw, bt, bo = bytearray(), [], []
-        for ti, p in enumerate(live):
-            st = self.state.get(p)
-            if st is None:
-                st = self.state[p] = (torch.zeros_like(p), torch.zeros_like(p))
-            raw += struct.pack("<QQQQq", p.data_ptr(), p.grad.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), p.numel())
-            for off in range(0, p.numel(), 1024):
-                bt.append(ti)
-                bo.append(off)
-        self._table = torch.frombuffer(raw, dtype=torch.uint8).to(dev)
-        self._bt = torch.tensor(bt, dtype=torch.int32, device=dev)
-        self._bo = torch.tensor(bo, dtype=torch.int64, device=dev)
-        self._sig = sig
+        shape_sig = tuple(id(p) for p in live)
+        if shape_sig != self._sig:
+            bt, bo = [], []
+            for ti, p in enumerate(live):
+                if p not in self.state:
+                    self.state[p] = (torch.zeros_like(p), torch.zeros_like(p))
+                nb = (p.numel() + 1023) // 1024
+                bt.append(torch.full((nb,), ti, dtype=torch.int32))
+                bo.append(torch.arange(nb, dtype=torch.int64) * 1024)
+            self._bt = torch.cat(bt).to(dev)
+            self._bo = torch.cat(bo).to(dev)
+            self._host = [torch.empty(40 * len(live), dtype=torch.uint8).pin_memory() for _ in range(2)]     # staging, double-buffered
+            self._host_ev = [None, None]
+            self._flip = 0
+            self._table = torch.empty(40 * len(live), dtype=torch.uint8, device=dev)
+            self._sig, self._ptr_sig = shape_sig, None
+        ptr_sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p in live)
+        if ptr_sig != self._ptr_sig:
+            raw = bytearray()
+            for p in live:
+                st = self.state[p]
+                raw += struct.pack("<QQQQq", p.data_ptr(), p.grad.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), p.numel())
+            k = self._flip = self._flip ^ 1
+            if self._host_ev[k] is not None:
+                self._host_ev[k].synchronize()          # the copy that last read this staging buffer (two steps ago) has completed
+            self._host[k].copy_(torch.frombuffer(raw, dtype=torch.uint8))
+            self._table.copy_(self._host[k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._host_ev[k] = ev
+            self._ptr_sig = ptr_sig
 
     @torch.no_grad()
     def step(self):
@@ -93,6 +112,32 @@ def train_step(model, optim, images, masks, reducer=None):
     return loss.detach(), jac, n
 
 
+def checkpoint_paths(pathm, i):
+    """the reference's checkpoint files: `iremmodel{i}.pt` rewritten after every epoch (F4_TRAIN.py:84) and
+    `Finaliremmodel{i}.pt` after the last one (F4_TRAIN.py:86); `validate` / `test_model` reload them (F4_TRAIN.py:180, F7_TEST2.py:126)"""
+    import os
+    return os.path.join(pathm, "iremmodel{}.pt".format(i)), os.path.join(pathm, "Finaliremmodel{}.pt".format(i))
+
+
+def train_model(n_epochs, model, scheduler, training_generator, optim, device, pathm, i, validation_generator=None, reducer=None):
+    """F4_TRAIN.py:39-86 restated: per epoch `train_epoch` (scheduler first), the per-epoch checkpoint `iremmodel{i}.pt`, validation;
+    `Finaliremmodel{i}.pt` at the end.  In a data-parallel job rank 0's BatchNorm buffers are broadcast before each save and rank 0
+    writes the file (data_parallel.save_checkpoint).  Returns the per-epoch (train loss, train Jaccard, val loss,
+    val Jaccard) the reference writes to its log files."""
+    from data_parallel import save_checkpoint
+    per_epoch, final = checkpoint_paths(pathm, i)
+    log = []
+    for _ in range(n_epochs):
+        tl, tj = train_epoch(model, optim, scheduler, training_generator, device, reducer)
+        save_checkpoint(model, per_epoch)
+        vl = vj = None
+        if validation_generator is not None:
+            vl, vj = evaluate(model, validation_generator, device)
+        log.append((tl, tj, vl, vj))
+    save_checkpoint(model, final)
+    return log
+
+
 def train_epoch(model, optim, scheduler, loader, device, reducer=None, checkpoint=None):
     model.train()
     scheduler.step()                                   # before the optimiser, as the reference does (F4_TRAIN.py:46)
@@ -103,7 +148,8 @@ def train_epoch(model, optim, scheduler, loader, device, reducer=None, checkpoin
         jI += jac.item()
         total += n
     if checkpoint:
-        torch.save(model.state_dict(), checkpoint)     # F4_TRAIN.py:84
+        from data_parallel import save_checkpoint
+        save_checkpoint(model, checkpoint)             # F4_TRAIN.py:84 (rank 0's buffers, written by rank 0)
     return sum(losses) / max(len(losses), 1), jI / max(total, 1)
 
 
@@ -125,25 +171,28 @@ def evaluate(model, loader, device):
 class GraphedForward:
     """Eval-mode forward captured ONCE per input shape in a HIP graph and replayed (the per-image metric loop runs at batch 1,
     where the ~2000 launches of a forward cost more host time than the GPU needs: a step is launch-bound, not MFMA-bound).
-    The module's multi-stream schedule is switched off for the capture (one stream; at batch 1 there is little to overlap).
-    Capturing the forked branch / lane / skip streams as well replays 1.9x faster than eager at batch 1 and is bit-identical,
-    but the process then segfaults inside the HIP runtime on the next eager forward or capture (observed twice on the MI355X
-    boxes, with and without `record_stream`), so it is not offered.  Results are bit-identical to the eager forward."""
+    The capture takes the module's real schedule - the three modality-branch streams, the sample-group lanes and the decoder's
+    skip stream fork from the capturing stream and re-join it - so the replay keeps their concurrency (1.9x faster than eager at
+    batch 1 in round 1, 1.24x for a single-stream capture).  Round 1 had to capture single-stream because the process crashed after
+    a multi-stream capture; the cause was events destroyed while their stream was still capturing (mmvit4._Edges explains it) and
+    is fixed by the model's persistent fork/join events.  `single_stream=True` still forces the one-stream schedule.
+    Results are bit-identical to the eager forward."""
 
-    def __init__(self, model, example, warmup=2):
+    def __init__(self, model, example, warmup=2, single_stream=False):
         model.eval()
         self.model = model
         self.static_in = example.detach().clone()
         saved = []
-        for obj, name, off in ((model, "concurrent_branches", False), (model, "decoder_split", 0),
-                               (getattr(model, "decoder_fuse", None), "concurrent_skips", False)):
-            if obj is not None and hasattr(obj, name):
-                saved.append((obj, name, getattr(obj, name)))
-                setattr(obj, name, off)
+        if single_stream:
+            for obj, name, off in ((model, "concurrent_branches", False), (model, "decoder_split", 0),
+                                   (getattr(model, "decoder_fuse", None), "concurrent_skips", False)):
+                if obj is not None and hasattr(obj, name):
+                    saved.append((obj, name, getattr(obj, name)))
+                    setattr(obj, name, off)
         try:
             side = torch.cuda.Stream(device=example.device)
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side), torch.no_grad():      # lazy initialisation (kernel attributes, streams, allocator pool) outside the capture
+            with torch.cuda.stream(side), torch.no_grad():      # lazy initialisation (kernel attributes, streams, fork/join events, allocator pool) outside the capture
                 for _ in range(warmup):
                     model(self.static_in)
             torch.cuda.current_stream().wait_stream(side)

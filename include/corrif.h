@@ -32,7 +32,7 @@ extern "C" {
 #define CORRIF_EUNSUPPORTED (-2)
 #define CORRIF_ELAUNCH (-3)
 
-#define CORRIF_ABI_VERSION 2   /* 2: CorrifConv3Patch.fold */
+#define CORRIF_ABI_VERSION 3   /* 2: CorrifConv3Patch.fold  3: CorrifGemm.ws / no_split (stream-K), corrif_scale, corrif_fill */
 int corrif_abi_version(void);
 /* name of the gfx target the library was built for ("gfx950") - host-only call */
 const char* corrif_build_arch(void);
@@ -96,8 +96,15 @@ typedef struct CorrifGemm {
      * chunks = ceil(stats_rows_per_group / 64); corrif_norm_stats_finalize turns them into mean / rstd.  Saves the
      * separate statistics pass over the conv output.  stats_rows_per_group must be a multiple of 64 unless it equals M. */
     double* stats_part; int64_t stats_rows_per_group; int32_t stats_relu;
+    /* Stream-K split (ABI 3).  When the tile grid would fill the resident workgroup slots of the chip unevenly (e.g. 392 tiles on
+     * 512 slots), the launch becomes a persistent grid whose workgroups each take an equal share of the (tile, K tile) iterations;
+     * tiles cut by a share boundary are completed by a second, fixed-order reduction kernel (deterministic, no atomics).  The caller
+     * provides `ws` with corrif_gemm_fwd_workspace(p) bytes (0 = this launch is not split; 16-byte aligned); no_split = 1 forces the
+     * one-workgroup-per-tile launch (A/B measurements). */
+    float* ws; int32_t no_split;
 } CorrifGemm;
 int corrif_gemm_fwd(const CorrifGemm* p, void* stream);
+size_t corrif_gemm_fwd_workspace(const CorrifGemm* p);   /* bytes of CorrifGemm.ws this launch needs; queries the device's CU count */
 
 /* W-type contraction over rows:  C[z][M,N] = sum_r A[r][M] * gather(B)[r][N]     N = taps*Cs
  * Replaces aten::convolution_backward's weight gradient (A = dY, B = layer input) for every
@@ -268,6 +275,10 @@ int corrif_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void*
 int corrif_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
 /* y = x * scalar[0], scalar on the device (upstream gradient of the scalar loss) */
 int corrif_scale_dev(const float* x, const float* scalar, float* y, int64_t n, void* stream);
+/* y = x * alpha (host scalar; the 1/world averaging of the data-parallel gradient buckets, x may alias y) ; y[:] = value
+ * (zeroing the gradient buckets): replace aten::mul_ / aten::zero_ on the training step's path */
+int corrif_scale(const float* x, float* y, int64_t n, float alpha, void* stream);
+int corrif_fill(float* y, int64_t n, float value, void* stream);
 /* strided 2-D copy / accumulate: dst[r*ldd + c] (+)= src[r*lds + c], c < C (torch.cat / chunk grads) */
 int corrif_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int32_t C, int32_t accumulate, void* stream);
 /* out[c] = sum over rows r of x[r*ld + c] for r in a group of `rows` (pos gradient: sum over batch) */

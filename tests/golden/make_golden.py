@@ -1,6 +1,6 @@
 """Generate the golden fixtures under tests/golden/ from the UPSTREAM reference (development container only).
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [case-name | train_trace ...]     (no argument: everything)
 
 Imports /root/reference/mmvit4.py and F5_JACCARD2.py (read-only tree; no bytecode written),
 with the topology-only torchvision stand-in of tests/golden/_tv_standin on sys.path ahead of it
@@ -39,7 +39,18 @@ CASES = [
     ("tame_eval_b3_d3_64", 3, 3, 64, 64, "eval", 1.0, 1),
     ("tame_train_b1_d4_224", 1, 4, 224, 224, "train_nodrop", 1.0, 2),
     ("kaiming_train_b2_d3_96", 2, 3, 96, 96, "train_nodrop", math.sqrt(2.0), 3),
+    # round 2: the BASELINE sizes.  configs[0] = batch 4, 4 bands, 224^2 (the one configuration the reference itself runs,
+    # F4_TRAIN.py:52-61); B = 3 at 224^2 (B | 3: the other branch of the inter-modal re-view); the reference's real init scale
+    # (kaiming_normal_, mmvit4.py:437-439) at 224^2 with B = 2 (non-trivial re-view and BatchNorm batch statistics)
+    # (fp32 only: the fp64 run of this case needs > 62 GB, more than the development container has; its fp64 truth is computed by
+    # the GPU tests with the oracle's modules on the device, which tests/test_model_gpu.py pins against the fp64 fixtures below)
+    ("tame_train_b4_d4_224", 4, 4, 224, 224, "train_nodrop", 1.0, 4),
+    ("tame_eval_b3_d3_224", 3, 3, 224, 224, "eval", 1.0, 5),
+    ("kaiming_train_b2_d4_224", 2, 4, 224, 224, "train_nodrop", math.sqrt(2.0), 6),
 ]
+
+
+FP32_ONLY = {"tame_train_b4_d4_224"}
 
 
 def sample(t, n=64):
@@ -87,7 +98,8 @@ def run_case(name, B, D, H, W, mode, gain, wseed, dtype):
 
     hs.append(model.multimodal_transformer.register_forward_pre_hook(pre))
     t0 = time.time()
-    pred = model(x)
+    with torch.set_grad_enabled(mode != "eval"):       # eval cases need no autograd state (B = 3 at 224^2 in fp64 would not fit otherwise)
+        pred = model(x)
     out = {"pred_sample": pred.detach()[:, :, 0, ::4, ::4].double().numpy(),
            "pred_sum": np.float64(pred.detach().double().sum().item()),
            "pred_sqsum": np.float64((pred.detach().double() ** 2).sum().item()),
@@ -134,17 +146,79 @@ def jaccard_cases():
     return out
 
 
+def train_trace(dtype, B=2, D=3, HW=64, wseed=7, steps=3, lr=1e-4, step_size=1, gamma=0.5):
+    """The training step of F4_TRAIN.py:41-71 with the optimiser of F2_MAIN.py:168-173 (torch.optim.Adam + StepLR, the scheduler
+    stepped BEFORE the optimiser, F4_TRAIN.py:46), on the upstream model, dropout modules in eval (masks cannot be matched).
+    step_size = 1 makes the scheduler quirk visible: the run uses lr * gamma from its first step on."""
+    torch.manual_seed(0)
+    model = ref_mmvit4.MMVit4()
+    model.load_state_dict(helpers.make_state_dict(model.state_dict(), seed=wseed, conv_gain=1.0))
+    model = model.to(dtype).train()
+    for m in model.modules():
+        if isinstance(m, nn.Dropout):
+            m.eval()
+    optim = torch.optim.Adam(model.parameters(), lr=lr)
+    sched = torch.optim.lr_scheduler.StepLR(optim, step_size=step_size, gamma=gamma)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sched.step()                                   # F4_TRAIN.py:46 - before any optimiser step
+    x, mask = helpers.make_inputs(B, D, HW, HW)
+    x, mask = x.to(dtype), mask.to(dtype)
+    n = B * 224 * 224
+    out = {"loss": [], "jaccard2": [], "lr": np.float64(optim.param_groups[0]["lr"])}
+    for _ in range(steps):
+        optim.zero_grad()
+        pred = model(x)
+        loss = nn.BCEWithLogitsLoss()(pred, mask)
+        loss.backward()
+        optim.step()
+        out["loss"].append(loss.item())
+        out["jaccard2"].append(ref_j2.Jaccard2(mask[:, 0].reshape(n, 1), pred.detach()[:, 0].reshape(n, 1)).double().item())
+    out["loss"], out["jaccard2"] = np.array(out["loss"]), np.array(out["jaccard2"])
+    sd = model.state_dict()
+    tot = 0.0
+    for k, v in sd.items():
+        if v.dtype.is_floating_point:
+            tot += v.double().abs().sum().item()
+    out["abs_sum_all"] = np.float64(tot)
+    for k in helpers.GRAD_KEYS + ["RGB_encoder.e1_bn.running_mean", "SWIR_encoder.e5.2.bn3.running_var"]:
+        out["param_sample/" + k] = sample(sd[k])
+        out["param_norm/" + k] = np.float64(sd[k].double().norm().item())
+    out["nbt"] = np.int64(int(sd["RGB_encoder.e1_bn.num_batches_tracked"]))
+    frozen = helpers.make_state_dict(sd, seed=wseed, conv_gain=1.0)
+    out["untouched"] = np.int64(sum(1 for k, v in model.named_parameters() if torch.equal(v.detach().float(), frozen[k])))
+    return out
+
+
 def main():
-    meta = {"torch": torch.__version__, "cases": []}
-    for (name, B, D, H, W, mode, gain, wseed) in CASES:
+    only = set(sys.argv[1:])
+    meta_path = os.path.join(HERE, "meta.json")
+    meta = json.load(open(meta_path)) if only and os.path.exists(meta_path) else {"torch": torch.__version__, "cases": []}
+    if not only or "train_trace" in only:
         blob = {}
-        for dtype in (torch.float32, torch.float64):
+        for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+            for k, v in train_trace(dtype).items():
+                blob[tag + "/" + k] = v
+        np.savez_compressed(os.path.join(HERE, "train_trace_b2_d3_64.npz"), **blob)
+        print("train trace", blob["f32/loss"], blob["f64/loss"], flush=True)
+    for (name, B, D, H, W, mode, gain, wseed) in CASES:
+        if only and name not in only:
+            continue
+        blob = {}
+        for dtype in (torch.float32,) if name in FP32_ONLY else (torch.float32, torch.float64):
             r = run_case(name, B, D, H, W, mode, gain, wseed, dtype)
             tag = "f32" if dtype == torch.float32 else "f64"
             for k, v in r.items():
                 blob[tag + "/" + k] = v
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **blob)
-        meta["cases"].append({"name": name, "B": B, "D": D, "H": H, "W": W, "mode": mode, "conv_gain": gain, "wseed": wseed})
+        meta["cases"] = [c for c in meta["cases"] if c["name"] != name]
+        meta["cases"].append({"name": name, "B": B, "D": D, "H": H, "W": W, "mode": mode, "conv_gain": gain, "wseed": wseed,
+                              "dtypes": ["f32"] if name in FP32_ONLY else ["f32", "f64"]})
+        with open(meta_path, "w") as f:
+            json.dump(meta, f, indent=1)
+    if only:
+        return
     np.savez_compressed(os.path.join(HERE, "jaccard.npz"), **jaccard_cases())
     # key / shape inventory of the reference state-dict (the drop-in contract, SURVEY section 8b)
     torch.manual_seed(0)

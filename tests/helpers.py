@@ -108,6 +108,11 @@ NOGRAD_PREFIXES = ("RGB_decode_conv.", "NIR_decode_conv.", "SWIR_decode_conv.", 
                    "decoder_fuse.seg_d3.", "decoder_fuse.seg_d4.", "decoder_fuse.seg_layer.", "fusion5.conv.")
 
 
+# the large BASELINE geometries at batch 2 (fixtures from the CPU oracle on the GPU box's host, tests/golden/make_golden_large.py):
+# name -> (B, bands per modality, H, W, weight seed); configs[2] = 8 bands 256^2, configs[4] = 12 bands 512^2
+LARGE_CASES = {"oracle_train_b2_d8_256": (2, 8, 256, 256, 41), "oracle_train_b2_d12_512": (2, 12, 512, 512, 42)}
+
+
 # the same for the sibling model MMVit2
 GRAD_KEYS_MMVIT2 = [
     "RGB_encoder.e1_c1.weight", "RGB_encoder.e1_c1.bias", "RGB_encoder.e1_c2.conv.weight", "RGB_encoder.e1_c3.conv.bias",

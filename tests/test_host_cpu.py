@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(built):
     assert set(corrif_hip.EXPORTS) == declared           # the ctypes mirror binds exactly the header's surface
     # host-only entry points are callable without a GPU
     lib.corrif_abi_version.restype = ctypes.c_int
-    assert lib.corrif_abi_version() == 2
+    assert lib.corrif_abi_version() == 3
     lib.corrif_build_arch.restype = ctypes.c_char_p
     assert lib.corrif_build_arch() == b"gfx950"
     lib.corrif_wgrad_plan.restype = ctypes.c_int
@@ -122,6 +122,21 @@ def test_philox_stream_bookkeeping(built):
     s1, o1 = ops._Philox.reserve(10)
     s2, o2 = ops._Philox.reserve(7)
     assert (s1, o1) == (42, 0) and (s2, o2) == (42, 12)       # offsets advance in multiples of 4 (one Philox block)
+    # the drop-in path never calls ops.manual_seed: the stream follows torch's default generator, so torch.manual_seed() re-keys it
+    # (and restarts the offset); ranks of a data-parallel job are decorrelated by their rank
+    ops.follow_torch_seed()
+    torch.manual_seed(123)
+    a, oa = ops._Philox.reserve(8)
+    _, ob = ops._Philox.reserve(8)
+    torch.manual_seed(124)
+    b, oc = ops._Philox.reserve(8)
+    torch.manual_seed(123)
+    c, od = ops._Philox.reserve(8)
+    assert a != b and a == c and (oa, ob, oc, od) == (0, 8, 0, 0)
+    ops.follow_torch_seed(rank=1)
+    d, _ = ops._Philox.reserve(8)
+    assert d != c
+    ops.follow_torch_seed()
 
 
 DP_WORKER = r'''
@@ -135,7 +150,11 @@ net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Line
 unused = torch.nn.Linear(3, 3); net.add_module("unused", unused)   # never receives a gradient (like the 18 tensors of MMVit4)
 broadcast_module_state(net)
 ref = [p.detach().clone() for p in net.parameters()]
-red = GradAllReducer(net, bucket_bytes=256)         # tiny buckets: several of them
+bn = torch.nn.BatchNorm1d(4); net.add_module("bn", bn)             # a buffer-carrying module: per-rank statistics
+bn.running_mean.fill_(float(rank + 1)); bn.weight.requires_grad_(False); bn.bias.requires_grad_(False)
+# rank 1 builds its buckets BEFORE the first backward from the declared grad-less set, rank 0 lazily after it: same buckets, same order
+red = GradAllReducer(net, bucket_bytes=256, skip_prefixes=("unused.",) if rank == 1 else None)         # tiny buckets: several of them
+prebuilt = (red.buckets is not None) == (rank == 1)
 torch.manual_seed(7)
 X, Y = torch.randn(8, 8), torch.randn(8, 4)
 outs = []
@@ -160,8 +179,13 @@ same_init = all(torch.equal(a, b) for a, b in zip(ref, [p.detach() for p in net.
 g0 = [torch.zeros(1) for _ in range(world)]
 dist.all_gather(g0, ref[0].sum().reshape(1))
 n_comm = red.communicated_elements()
-n_live = sum(p.numel() for p in net.parameters()) - sum(p.numel() for p in unused.parameters())
-print("RESULT", rank, ok, same_init, bool(g0[0] == g0[1]), len(red.buckets) > 1, n_comm == n_live, flush=True)
+n_live = sum(p.numel() for p in net.parameters() if p.requires_grad) - sum(p.numel() for p in unused.parameters())
+from data_parallel import save_checkpoint
+ck = os.path.join(sys.argv[3], "iremmodel0.pt")
+save_checkpoint(net, ck)                            # SURVEY 8(e): rank 0's buffers on every rank, one file, written by rank 0
+sd = torch.load(ck)
+buf_ok = float(bn.running_mean[0]) == 1.0 and float(sd["bn.running_mean"][0]) == 1.0
+print("RESULT", rank, ok, same_init, bool(g0[0] == g0[1]), len(red.buckets) > 1, n_comm == n_live, prebuilt, buf_ok, flush=True)
 dist.destroy_process_group()
 '''
 
@@ -175,10 +199,10 @@ def test_data_parallel_gloo_world2(built, tmp_path):
     procs = []
     for r in range(2):
         e = dict(env, RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, str(script), helpers.PKG, helpers.ROOT], env=e, stdout=subprocess.PIPE,
+        procs.append(subprocess.Popen([sys.executable, str(script), helpers.PKG, helpers.ROOT, str(tmp_path)], env=e, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, o in enumerate(outs):
         line = [l for l in o.splitlines() if l.startswith("RESULT")]
         assert line, o
-        assert line[0].split()[2:] == ["True"] * 5, o
+        assert line[0].split()[2:] == ["True"] * 7, o

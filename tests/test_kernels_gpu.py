@@ -98,6 +98,49 @@ def test_conv3d(ops, cfg):
         assert rel(bg.grad, br.grad) < 2e-6, "bias gradient"
 
 
+SPLIT_CASES = [
+    # name, M, N, K, b_layout: shapes whose tile grid fills the chip unevenly -> stream-K split (persistent workgroups + fixed-order fixup)
+    ("e4_conv_like_392_tiles", 25088, 256, 1152, 0),
+    ("e5_like_196_tiles_long_k", 6272, 512, 2304, 0),
+    ("few_tiles_long_k_KN_operand", 1024, 384, 4096, 1),
+    ("ragged_edges", 3000, 200, 1000, 0),
+]
+
+
+@pytest.mark.parametrize("cfg", SPLIT_CASES, ids=[c[0] for c in SPLIT_CASES])
+def test_gemm_stream_k_split(ops, cfg):
+    """The stream-K launch (equal shares of the (tile, K tile) space per persistent workgroup, partial tiles summed in a fixed order by
+    the fixup kernel) against an fp64 matmul; it must actually be split (workspace > 0), be bit-identical run to run, and agree with
+    the one-workgroup-per-tile launch of the same kernel to fp32 rounding (the K sum is associated differently)."""
+    import corrif_hip as H
+    _, M, N, K, bl = cfg
+    A = rnd(M, K, seed=11).to(DEV)
+    Bm = (rnd(N, K, seed=12) / math.sqrt(K)).to(DEV)
+    Bop = Bm.t().contiguous() if bl else Bm
+    bias = rnd(N, seed=13).to(DEV)
+    ref = (A.double() @ Bm.double().t() + bias.double()).cpu()
+
+    def run():
+        C = torch.empty(M, N, device=DEV)
+        ops.gemm(A.data_ptr(), K, Bop.data_ptr(), N if bl else K, bl, C.data_ptr(), N, M, N, K, K, H.gemm_geom(), bias=bias.data_ptr())
+        return C
+
+    g = H.Gemm()
+    g.A, g.lda, g.Cs, g.B, g.ldb, g.b_layout, g.C, g.ldc = A.data_ptr(), K, K, Bop.data_ptr(), (N if bl else K), bl, A.data_ptr(), N
+    g.M, g.N, g.K, g.Z, g.Zi, g.g = M, N, K, 1, 1, H.gemm_geom()
+    assert H.lib().corrif_gemm_fwd_workspace(g) > 0, "this shape is expected to take the stream-K path"
+    c1, c2 = run(), run()
+    ops.STREAM_K = False
+    try:
+        c0 = run()
+    finally:
+        ops.STREAM_K = True
+    torch.cuda.synchronize()
+    assert torch.equal(c1, c2)
+    assert rel(c1, ref) < 2e-6 and rel(c0, ref) < 2e-6
+    assert rel(c1, c0) < 1e-6
+
+
 def test_conv3d_sliced_io(ops):
     """input is a channel slice of a wider buffer and the output is written into a slice (in-place concat)."""
     B, D, Hh, W, Ci, Co = 2, 3, 6, 6, 16, 24

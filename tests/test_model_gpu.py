@@ -52,7 +52,9 @@ def run_hip(case):
     return model, pred, mask, loss, sd
 
 
-@pytest.mark.parametrize("name", ["tame_train_b2_d3_64", "tame_eval_b3_d3_64", "tame_train_b1_d4_224"])
+# tame_eval_b3_d3_224: B | 3 at 224^2 (the other branch of the inter-modal re-view, mmvit4.py:481-491).  BASELINE configs[0]
+# (tame_train_b4_d4_224) is checked by test_large_baseline_configs_fwd_bwd: its fp64 reference run does not fit the development container.
+@pytest.mark.parametrize("name", ["tame_train_b2_d3_64", "tame_eval_b3_d3_64", "tame_train_b1_d4_224", "tame_eval_b3_d3_224"])
 def test_against_reference_fixture_tame(name):
     import mmvit4
     case = CASES[name]
@@ -93,11 +95,13 @@ def test_against_reference_fixture_tame(name):
         assert int(sd["RGB_encoder.e1_bn.num_batches_tracked"]) == 1
 
 
-def test_against_reference_fixture_kaiming_bracketed():
-    """kaiming-scale weights: activations reach 1e3-1e4 and the 3-way correlation softmax saturates, so the bar is
-    k x the reference's own fp32-vs-fp64 error, k = 5; soft Jaccard stays within 1e-5."""
+@pytest.mark.parametrize("name", ["kaiming_train_b2_d3_96", "kaiming_train_b2_d4_224"])
+def test_against_reference_fixture_kaiming_bracketed(name):
+    """The reference's REAL init scale (kaiming_normal_, mmvit4.py:437-439), also at the BASELINE size 224^2 with B = 2 (non-trivial
+    inter-modal re-view and BatchNorm batch statistics).  Activations reach 1e3-1e4 and the 3-way correlation softmax saturates, so
+    the bar is k x the reference's own fp32-vs-fp64 error, k = 5, for the prediction AND for every sampled gradient and
+    gradient norm of helpers.GRAD_KEYS (45 tensors covering every kernel family); soft Jaccard stays within 1e-5."""
     import mmvit4
-    name = "kaiming_train_b2_d3_96"
     case = CASES[name]
     g = np.load(os.path.join(helpers.GOLDEN, name + ".npz"))
     model, pred, mask, loss, _ = run_hip(case)
@@ -107,7 +111,76 @@ def test_against_reference_fixture_kaiming_bracketed():
     n = case["B"] * 224 * 224
     j = mmvit4.Jaccard2(mask[:, 0].reshape(n, 1).to(DEV), pred.detach()[:, 0].reshape(n, 1)).cpu().numpy()
     assert abs(float(j[0]) - float(g["f64/jaccard2"][0])) < 1e-5
-    assert abs(loss.item() - float(g["f64/loss"])) < 1e-4
+    assert abs(loss.item() - float(g["f64/loss"])) < max(1e-4, 5 * abs(float(g["f32/loss"]) - float(g["f64/loss"])))
+    params = dict(model.named_parameters())
+    bad = []
+    for k in helpers.GRAD_KEYS:
+        ref = g["f64/grad_sample/" + k]
+        got = sample(params[k].grad)
+        scale = max(np.abs(ref).max(), 1e-30)
+        err = np.abs(got - ref).max() / scale
+        ref32 = np.abs(g["f32/grad_sample/" + k] - ref).max() / scale            # the reference's own fp32 error on these samples
+        nr = float(g["f64/grad_norm/" + k])
+        nerr = abs(params[k].grad.double().norm().item() - nr) / max(nr, 1e-30)
+        n32 = abs(float(g["f32/grad_norm/" + k]) - nr) / max(nr, 1e-30)
+        if err > max(5 * ref32, 2e-3) or nerr > max(5 * n32, 1e-2):      # norm floor 1e-2 as for the tame fixtures
+
+            bad.append((k, err, ref32, nerr, n32))
+    assert not bad, bad
+    nog = [k for k, p in params.items() if p.grad is None]
+    assert len(nog) == 18 and all(k.startswith(helpers.NOGRAD_PREFIXES) for k in nog)
+
+
+def _ncdhw_sample(t, n=256):
+    """sample() of the golden generator on the reference's NCDHW layout, for a channels-last [B, D, H, W, C] activation (tokens
+    [B, N, C] are laid out identically in both)"""
+    if t.dim() == 5:
+        t = t.permute(0, 4, 1, 2, 3).contiguous()
+    return sample(t, n)
+
+
+@pytest.mark.parametrize("name", ["tame_train_b2_d3_64", "tame_eval_b3_d3_224", "kaiming_train_b2_d4_224"])
+def test_stage_taps_against_reference_fixture(name):
+    """Per-stage parity: nine intermediate activations (first encoder layer, last encoder layer, an early-fusion block, an
+    intra-modality transformer, the correlation's qkv conv, the multimodal transformer's input and output, x6_inter, a decoder
+    stage at 16^3 and the last one at 128^3) captured from the reference with forward hooks, so a regression is located at its
+    stage and not only seen at the sigmoid output.  Bar per tap: max error relative to the tap's largest value <= 5 x the
+    reference's own fp32-vs-fp64 figure (floor 2e-5; kaiming: 1e-3)."""
+    case = CASES[name]
+    g = np.load(os.path.join(helpers.GOLDEN, name + ".npz"))
+    model, _ = build_hip(case)
+    model.decoder_split = 0                      # one lane: module hooks then see whole-batch tensors like the reference's
+    taps = {}
+
+    def grab(key):
+        def hook(mod, inp, out):
+            taps[key] = _ncdhw_sample(out)
+        return hook
+
+    def pre(mod, inp):
+        taps["mm_in"] = _ncdhw_sample(inp[0])
+
+    d = model.decoder_fuse
+    for key, mod in (("tap_RGB_e2", model.RGB_encoder.e2), ("tap_SWIR_e5", model.SWIR_encoder.e5), ("tap_fusion3", model.fusion3),
+                     ("tap_NIR_transformer", model.NIR_transformer), ("tap_qkv_RGB", model.qkv_RGB),
+                     ("tap_mm_transformer", model.multimodal_transformer), ("tap_x6_inter", model.multimodal_decode_conv),
+                     ("tap_d4_c2", d.d4_c2), ("tap_d1_out", d.d1_out)):
+        mod.register_forward_hook(grab(key))
+    model.multimodal_transformer.register_forward_pre_hook(pre)
+    x, _ = helpers.make_inputs(case["B"], case["D"], case["H"], case["W"])
+    with torch.no_grad():
+        model(x.to(DEV))
+    torch.cuda.synchronize()
+    floor = 1e-3 if name.startswith("kaiming") else 2e-5
+    bad = []
+    for key in sorted(taps):
+        r64, r32 = g["f64/" + key], g["f32/" + key]
+        scale = max(np.abs(r64).max(), 1e-30)
+        err = np.abs(taps[key] - r64).max() / scale
+        gap = np.abs(r32 - r64).max() / scale
+        if err > max(5 * gap, floor):
+            bad.append((key, err, gap))
+    assert len(taps) == 10 and not bad, bad
 
 
 def test_full_gradient_against_oracle():
@@ -171,6 +244,115 @@ def test_other_baseline_configs_forward(B, D, HW):
         pr = ref(x)
     assert pg.shape == (B, 3, 1, 224, 224)
     assert (pg.cpu() - pr).abs().max().item() < 1.5e-4
+
+
+def _oracle_on_device(case, dtype, sd, device=DEV):
+    """The oracle's module tree (stock torch ops, oracle/mmvit4_oracle.py) evaluated ON THE GPU BOX'S DEVICE in `dtype`: forward +
+    loss + backward in train-nodrop mode.  Used as the checker where the CPU would need hours (12 bands 512^2: the fp64 CPU run of
+    the 8-band case alone takes > 20 min on the box's host share).  test_device_oracle_is_pinned_by_the_reference_fixture ties this
+    evaluation to the upstream reference's own fp64 numbers."""
+    from oracle import mmvit4_oracle as O
+    ref = O.MMVit4()
+    ref.load_state_dict(sd)
+    ref = ref.to(device=device, dtype=dtype).train()
+    O.set_dropout(ref, False)
+    x, mask = helpers.make_inputs(case["B"], case["D"], case["H"], case["W"])
+    x, mask = x.to(device=device, dtype=dtype), mask.to(device=device, dtype=dtype)
+    pred = ref(x)
+    loss = O.train_step_loss(pred, mask)
+    loss.backward()
+    torch.cuda.synchronize()
+    out = {"pred_sample": pred.detach()[:, :, 0, ::4, ::4].double().cpu().numpy(), "loss": loss.item(),
+           "grads": {k: p.grad.double() for k, p in ref.named_parameters() if k in helpers.GRAD_KEYS},
+           "bufs": {k: ref.state_dict()[k].double().cpu() for k in ("RGB_encoder.e1_bn.running_mean", "SWIR_encoder.e5.2.bn3.running_var")}}
+    n = case["B"] * 224 * 224
+    out["jaccard2"] = helpers.jaccard2_ref(mask[:, 0].reshape(n, 1), pred.detach()[:, 0].reshape(n, 1)).item()
+    del ref, pred, loss
+    torch.cuda.empty_cache()
+    return out
+
+
+def test_device_oracle_is_pinned_by_the_reference_fixture():
+    """The fp64 device evaluation of the oracle reproduces the upstream reference's own fp64 run (fixture captured by importing the
+    reference, tests/golden/make_golden.py) to 1e-9 on the prediction and 1e-7 relative on sampled gradients: it is a valid 'truth'
+    for the sizes below."""
+    name = "tame_train_b2_d3_64"
+    case = CASES[name]
+    g = np.load(os.path.join(helpers.GOLDEN, name + ".npz"))
+    from oracle import mmvit4_oracle as O
+    sd = helpers.make_state_dict(O.MMVit4().state_dict(), seed=case["wseed"], conv_gain=case["conv_gain"])
+    r = _oracle_on_device(case, torch.float64, sd)
+    assert np.abs(r["pred_sample"] - g["f64/pred_sample"]).max() < 1e-9
+    assert abs(r["loss"] - float(g["f64/loss"])) < 1e-10
+    for k in helpers.GRAD_KEYS:
+        ref = g["f64/grad_sample/" + k]
+        got = sample(r["grads"][k])
+        assert np.abs(got - ref).max() <= 1e-7 * max(np.abs(ref).max(), 1e-30), k
+
+
+@pytest.mark.parametrize("name,force_single_stream", [("tame_train_b4_d4_224", False), ("oracle_train_b2_d8_256", True),
+                                                      ("oracle_train_b2_d12_512", False)])
+def test_large_baseline_configs_fwd_bwd(name, force_single_stream, monkeypatch):
+    """BASELINE configs[0] (batch 4, 4 bands, 224^2: the one configuration the reference itself runs, F4_TRAIN.py:52-61; fixture =
+    the upstream reference's own fp32 run), configs[2] (8 bands, 256^2) and configs[4] (12 bands, 512^2) geometry, forward AND
+    backward, at batch >= 2 (so the inter-modal re-view and the BatchNorm batch statistics are non-trivial).  Truth = the oracle's modules evaluated on the device in
+    fp64 (pinned by the test above), bracket = the same in fp32 (the reference's arithmetic); the 8-band case is additionally checked
+    against a fixture the CPU oracle produced in fp32 on the GPU box's host (tests/golden/make_golden_large.py, 12 min of host time).
+    The 8-band case runs through the single-stream schedule `MMVit4.forward` falls back to near the HBM capacity (what configs[2] at
+    B = 64 and configs[4] at B = 16 actually execute), forced here by patching the memory estimate.  Brackets as for the reference
+    fixtures: 3x the fp32 arithmetic's own error against fp64 for the prediction, 10x (floor 1e-3) for the sampled gradients."""
+    import mmvit4
+    if name in helpers.LARGE_CASES:
+        B, D, H, W, wseed = helpers.LARGE_CASES[name]
+        case = dict(B=B, D=D, H=H, W=W, mode="train_nodrop", conv_gain=1.0, wseed=wseed)
+    else:
+        case = CASES[name]
+        B = case["B"]
+    if force_single_stream:
+        monkeypatch.setattr(mmvit4, "_memory_limited", lambda x, frac=0.6: True)
+    model, pred, mask, loss, sd = run_hip(case)
+    assert model.concurrent_branches and model.decoder_split == 2          # the fall-back restores the switches
+    ps = pred.detach()[:, :, 0, ::4, ::4].double().cpu().numpy()
+    n = B * 224 * 224
+    jac = mmvit4.Jaccard2(mask[:, 0].reshape(n, 1).to(DEV), pred.detach()[:, 0].reshape(n, 1)).cpu().numpy()
+    hip_loss = loss.item()
+    grads = {k: p.grad.double().cpu() for k, p in model.named_parameters() if k in helpers.GRAD_KEYS}
+    bufs = {k: v.double().cpu() for k, v in model.state_dict().items() if k in ("RGB_encoder.e1_bn.running_mean", "SWIR_encoder.e5.2.bn3.running_var")}
+    assert sum(1 for p in model.parameters() if p.grad is None) == 18
+    del model, pred, loss
+    torch.cuda.empty_cache()
+    r32 = _oracle_on_device(case, torch.float32, sd)
+    r32g = {k: v.cpu() for k, v in r32["grads"].items()}
+    r32["grads"] = None
+    r64 = _oracle_on_device(case, torch.float64, sd)
+    gap = np.abs(r32["pred_sample"] - r64["pred_sample"]).max()
+    assert np.abs(ps - r64["pred_sample"]).max() < max(3 * gap, 5e-5), (np.abs(ps - r64["pred_sample"]).max(), gap)
+    assert abs(float(jac[0]) - r64["jaccard2"]) < 1e-5
+    assert abs(hip_loss - r64["loss"]) < max(1e-5, 3 * abs(r32["loss"] - r64["loss"]))
+    bad = []
+    for k in helpers.GRAD_KEYS:
+        t = r64["grads"][k].cpu()
+        nrm = t.norm().clamp_min(1e-30)
+        e_hip = ((grads[k] - t).norm() / nrm).item()
+        e_ref = ((r32g[k] - t).norm() / nrm).item()
+        if e_hip > max(10 * e_ref, 1e-3):
+            bad.append((k, e_hip, e_ref))
+    assert not bad, bad
+    for k, b in bufs.items():
+        t = r64["bufs"][k]
+        assert ((b - t).norm() / t.norm()).item() < max(3 * ((r32["bufs"][k] - t).norm() / t.norm()).item(), 1e-4), k
+    path = os.path.join(helpers.GOLDEN, name + ".npz")
+    if os.path.exists(path):                     # the fp32 run of the same case by the upstream reference (configs[0]) / by the CPU oracle on the
+        g = np.load(path)                        # GPU box's host cores (8 bands): the device fp32 evaluation must reproduce it, HIP must bracket it
+        assert np.abs(r32["pred_sample"] - g["f32/pred_sample"]).max() < max(gap, 2e-5)
+        assert np.abs(ps - g["f32/pred_sample"]).max() < max(4 * gap, 5e-5)
+        assert abs(hip_loss - float(g["f32/loss"])) < max(1e-5, 4 * abs(r32["loss"] - r64["loss"]))
+        for k in helpers.GRAD_KEYS:              # sampled gradients of the fixture against the fp64 truth: same bracket
+            t = sample(r64["grads"][k])
+            scale = max(np.abs(t).max(), 1e-30)
+            e_fix = np.abs(g["f32/grad_sample/" + k] - t).max() / scale
+            e_hip = np.abs(sample(grads[k]) - t).max() / scale
+            assert e_hip < max(10 * e_fix, 1e-3), (k, e_hip, e_fix)
 
 
 def test_module_surface():

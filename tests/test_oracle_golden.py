@@ -50,7 +50,8 @@ def run_oracle(case, dtype):
 
 
 # one fp32 case per mode keeps the CPU suite short; the others are exercised by make_golden's own asserts
-@pytest.mark.parametrize("name", ["tame_train_b2_d3_64", "tame_eval_b3_d3_64", "kaiming_train_b2_d3_96"])
+# tame_train_b4_d4_224 = BASELINE configs[0] (batch 4, 4 bands, 224^2), the configuration the reference itself runs on the CPU
+@pytest.mark.parametrize("name", ["tame_train_b2_d3_64", "tame_eval_b3_d3_64", "kaiming_train_b2_d3_96", "tame_train_b4_d4_224"])
 def test_oracle_matches_reference_fixture(name):
     case = CASES[name]
     g = np.load(os.path.join(helpers.GOLDEN, name + ".npz"))
@@ -86,3 +87,36 @@ def test_fixture_self_consistency_fp32_vs_fp64():
     gap = np.abs(g["f32/pred_sample"] - g["f64/pred_sample"]).max()
     assert gap < 1e-3
     assert abs(float(g["f32/jaccard2"][0]) - float(g["f64/jaccard2"][0])) < 1e-5
+
+
+def test_oracle_train_trace_matches_reference_fixture():
+    """The training step the tests and bench.py restate (F4_TRAIN.py:54-71 + Adam/StepLR of F2_MAIN.py:168-173) on the oracle equals
+    the trace captured from the upstream model: same ATen ops in the same order, so losses agree to the last bits."""
+    g = np.load(os.path.join(helpers.GOLDEN, "train_trace_b2_d3_64.npz"))
+    torch.manual_seed(0)
+    model = O.MMVit4()
+    model.load_state_dict(helpers.make_state_dict(model.state_dict(), seed=7, conv_gain=1.0))
+    model.train()
+    O.set_dropout(model, False)
+    optim = torch.optim.Adam(model.parameters(), lr=1e-4)
+    sched = torch.optim.lr_scheduler.StepLR(optim, step_size=1, gamma=0.5)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sched.step()                                  # before the optimiser (F4_TRAIN.py:46)
+    x, mask = helpers.make_inputs(2, 3, 64, 64)
+    n = 2 * 224 * 224
+    for i in range(3):
+        optim.zero_grad()
+        pred = model(x)
+        loss = O.train_step_loss(pred, mask)
+        loss.backward()
+        optim.step()
+        assert abs(loss.item() - float(g["f32/loss"][i])) < 2e-6, i
+        j = helpers.jaccard2_ref(mask[:, 0].reshape(n, 1), pred.detach()[:, 0].reshape(n, 1)).item()
+        assert abs(j - float(g["f32/jaccard2"][i])) < 1e-6
+    assert optim.param_groups[0]["lr"] == pytest.approx(float(g["f32/lr"]))
+    sd = model.state_dict()
+    for k in ("decoder_fuse.d1_c2.conv.weight", "RGB_encoder.e2.0.conv1.weight", "fused6_pos"):
+        np.testing.assert_allclose(sample(sd[k]), g["f32/param_sample/" + k], rtol=0, atol=2e-5)   # Adam: +-lr moves on sign noise
+    assert int(sd["RGB_encoder.e1_bn.num_batches_tracked"]) == int(g["f32/nbt"]) == 3

@@ -89,6 +89,76 @@ def test_train_steps_follow_the_oracle():
         assert moved != k.startswith(helpers.NOGRAD_PREFIXES), k
 
 
+def test_train_trace_against_reference_fixture(tmp_path):
+    """N1's pin: three consecutive steps of F4_TRAIN.py:54-71 with the optimiser of F2_MAIN.py:168-173 - the
+    upstream model + torch.optim.Adam + StepLR stepped BEFORE the optimiser (F4_TRAIN.py:46; step_size 1 / gamma 0.5 so that the quirk
+    shows: the run uses lr/2 from its first step) - captured from the reference in fp32 and fp64 (tests/golden/make_golden.py
+    train_trace): per-step loss and soft Jaccard, post-step parameter samples / norms, the sum of |every state-dict entry|, the
+    BatchNorm counter, the number of untouched parameters.  The HIP path runs the same three steps through train.train_model
+    (FusedAdam, StepLR, the reference's checkpoint names).  Step 1 agrees to fp32 noise; afterwards Adam turns sign noise on
+    near-zero gradients into +-lr moves, so steps 2-3 and the final parameters are bracketed by the reference's own fp32-vs-fp64
+    difference (x5) with a floor of 2 * steps * lr on single weights."""
+    import os
+    import numpy as np
+    import train
+    g = np.load(os.path.join(helpers.GOLDEN, "train_trace_b2_d3_64.npz"))
+    _, hip = _models(7, True)
+    x, mask = helpers.make_inputs(2, 3, 64, 64)
+    optim = train.FusedAdam(hip.parameters(), lr=1e-4)
+    sched = train.StepLR(optim, 1, 0.5)
+
+    class Loader:                                    # three batches of one epoch, the same tensors each time
+        def __iter__(self):
+            return iter([(x, mask)] * 3)
+
+    losses, jacs = [], []
+    orig = train.train_step
+
+    def spy(*a, **kw):
+        loss, jac, n = orig(*a, **kw)
+        losses.append(loss.item())
+        jacs.append(jac.item() / n)
+        return loss, jac, n
+
+    train.train_step = spy
+    try:
+        log = train.train_model(1, hip, sched, Loader(), optim, DEV, str(tmp_path), 4)
+    finally:
+        train.train_step = orig
+    assert optim.lr == pytest.approx(float(g["f64/lr"])) == pytest.approx(5e-5)
+    l64, l32 = g["f64/loss"], g["f32/loss"]
+    assert abs(losses[0] - l64[0]) < max(2e-6, 3 * abs(l32[0] - l64[0]))
+    for i in (1, 2):
+        assert abs(losses[i] - l64[i]) < max(2e-5, 5 * abs(l32[i] - l64[i])), (i, losses, l64, l32)
+        assert abs(jacs[i] - g["f64/jaccard2"][i]) < max(1e-5, 5 * abs(g["f32/jaccard2"][i] - g["f64/jaccard2"][i]))
+    assert abs(jacs[0] - g["f64/jaccard2"][0]) < 1e-5
+    assert abs(log[0][0] - float(np.mean(l64))) < 1e-4                      # epoch mean of the batch losses (F4_TRAIN.py:73)
+    per_epoch, final = train.checkpoint_paths(str(tmp_path), 4)
+    assert os.path.basename(per_epoch) == "iremmodel4.pt" and os.path.basename(final) == "Finaliremmodel4.pt"
+    sd = torch.load(final, map_location="cpu")
+    assert list(sd.keys()) == list(hip.state_dict().keys()) and os.path.exists(per_epoch)
+    assert int(sd["RGB_encoder.e1_bn.num_batches_tracked"]) == int(g["f64/nbt"]) == 3
+    floor = 2 * 3 * 5e-5
+    bad = []
+    for k in helpers.GRAD_KEYS + ["RGB_encoder.e1_bn.running_mean", "SWIR_encoder.e5.2.bn3.running_var"]:
+        ref, r32 = g["f64/param_sample/" + k], g["f32/param_sample/" + k]
+        f = sd[k].reshape(-1)
+        idx = (torch.arange(min(64, f.numel()), dtype=torch.int64) * (f.numel() - 1)) // max(min(64, f.numel()) - 1, 1)
+        got = f[idx].double().numpy()
+        err, e32 = np.abs(got - ref).max(), np.abs(r32 - ref).max()
+        nr = float(g["f64/param_norm/" + k])
+        nerr, n32 = abs(sd[k].double().norm().item() - nr), abs(float(g["f32/param_norm/" + k]) - nr)
+        if err > max(5 * e32, floor) or nerr > max(5 * n32, 1e-4 * nr + 1e-6):
+            bad.append((k, err, e32, nerr, n32))
+    assert not bad, bad
+    tot = sum(v.double().abs().sum().item() for v in sd.values() if v.dtype.is_floating_point)
+    t64, t32 = float(g["f64/abs_sum_all"]), float(g["f32/abs_sum_all"])
+    assert abs(tot - t64) < max(5 * abs(t32 - t64), 1e-6 * t64)
+    frozen = helpers.make_state_dict(sd, seed=7, conv_gain=1.0)
+    untouched = sum(1 for k, _ in hip.named_parameters() if torch.equal(sd[k], frozen[k]))
+    assert untouched == int(g["f64/untouched"]) == 18
+
+
 def test_eval_path_and_per_image_metrics():
     import train
     ref, hip = _models(22, False)
@@ -146,8 +216,10 @@ def test_reducer_rccl_path_single_rank():
 
 
 def test_hip_graph_eval_forward_is_bit_identical_to_eager():
-    """train.GraphedForward: the eval forward captured in a HIP graph (batch-1 metric loop) replays to the eager result,
-    also for a second input written into the static buffer, and leaves the module's multi-stream switches untouched."""
+    """train.GraphedForward: the eval forward captured in a HIP graph WITH the module's multi-stream schedule (branch streams,
+    sample-group lanes, decoder skip stream) replays to the eager result, also for a second input written into the static buffer;
+    an eager forward and a second (single-stream) capture AFTER it still work - that sequence crashed the process in round 1,
+    when fork/join events were destroyed while their stream was capturing (mmvit4._Edges)."""
     import train
     _, hip = _models(seed=21, train=False)
     x1, _ = helpers.make_inputs(1, 3, 64, 64, seed=1)
@@ -160,6 +232,13 @@ def test_hip_graph_eval_forward_is_bit_identical_to_eager():
     assert torch.equal(g(x1), e1)
     assert torch.equal(g(x2), e2)
     assert torch.equal(g(x1), e1)
+    with torch.no_grad():
+        assert torch.equal(hip(x2), e2)                   # eager forward after the multi-stream capture
+    g1 = train.GraphedForward(hip, x2, single_stream=True)
+    assert hip.concurrent_branches and hip.decoder_split == 2 and hip.decoder_fuse.concurrent_skips
+    assert torch.equal(g1(x1), e1)
+    assert torch.equal(g(x2), e2)                         # the first graph is still replayable
+    torch.cuda.synchronize()
 
 
 def test_bench_two_rank_control_flow_rehearsal():
