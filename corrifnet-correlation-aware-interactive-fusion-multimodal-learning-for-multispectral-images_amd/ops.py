@@ -54,7 +54,11 @@ def _ws(nbytes, dev):
     return H.ws_bytes(nbytes, dev)
 
 
-STREAM_K = True       # diagnostics / A-B: False launches every GEMM as one workgroup per tile
+# Stream-K split of gemm_fwd launches whose tile grid fills the chip unevenly (corrif_gemm_fwd_workspace / CorrifGemm.ws).  Off by
+# default: measured on the B=32 step it is a wash in kernel time (rocprofv3, serial schedule: 118.6 vs 124.4 ms for the family) and
+# a loss in wall time (304.9 vs 300.7 ms per step): the branch streams already fill the tails, short-K shapes pay more for the slab
+# round trip than they gain, and every launch costs a second descriptor call on the host.
+STREAM_K = False
 
 
 def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, addend=None, ld_add=0, act=ACT_NONE,
@@ -83,10 +87,11 @@ def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, add
     g.g = geom
     g.no_split = 0 if STREAM_K else 1
     buf = None
-    nws = lib().corrif_gemm_fwd_workspace(g)          # stream-K split: slabs for the tiles a share boundary cuts
-    if nws:
-        buf = _ws(nws, torch.device("cuda", torch.cuda.current_device()))
-        g.ws = buf.data_ptr()
+    if STREAM_K:
+        nws = lib().corrif_gemm_fwd_workspace(g)      # stream-K split: slabs for the tiles a share boundary cuts
+        if nws:
+            buf = _ws(nws, torch.device("cuda", torch.cuda.current_device()))
+            g.ws = buf.data_ptr()
     check(lib().corrif_gemm_fwd(g, stream()), "corrif_gemm_fwd")
 
 

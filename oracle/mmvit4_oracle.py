@@ -167,6 +167,22 @@ class Decoder(nn.Module):
     def _up2(t):
         return F.interpolate(t, scale_factor=2, mode="trilinear", align_corners=True)
 
+    @staticmethod
+    def _nearest(t, size):
+        """F.interpolate(t, size) (nearest, mmvit4.py:271,276,281,286).  On the CPU that is exactly what runs.  When the tests evaluate
+        this module on the GPU box's device (sizes the host would need hours for), ATen's device kernel for the BACKWARD of
+        upsample_nearest3d assigns output voxels to sources by ceil(i * out/in) in floating point, which is not the adjoint of its own
+        forward floor(o * in/out) when out/in is inexact (128/56: output row 16 is read from source 7 but its gradient goes to source
+        6).  The CPU kernel - what the reference runs - scatters with the forward's index.  So on a device the same forward indices
+        are applied with index_select, whose backward is the exact adjoint."""
+        if not t.is_cuda:
+            return F.interpolate(t, size)
+        for ax, (n_in, n_out) in enumerate(zip(t.shape[2:], size)):
+            scale = torch.tensor(float(n_in), dtype=torch.float32) / torch.tensor(float(n_out), dtype=torch.float32)
+            idx = torch.floor(torch.arange(n_out, dtype=torch.float32) * scale).long().clamp_(max=n_in - 1)
+            t = t.index_select(2 + ax, idx.to(t.device))
+        return t
+
     def forward(self, x1, x2, x3, x4, x5):
         y = self.d4_c1(self._up2(self.RFM5_reduce(self.RFM5(x5))))
         for rfm, skip, size, c2, out, c1 in (
@@ -175,7 +191,7 @@ class Decoder(nn.Module):
             (self.RFM2, x2, 64, self.d2_c2, self.d2_out, self.d1_c1),
             (self.RFM1, x1, 128, self.d1_c2, self.d1_out, None),
         ):
-            s = F.interpolate(rfm(skip), (size, size, size))           # nearest, mmvit4.py:271,276,281,286
+            s = self._nearest(rfm(skip), (size, size, size))
             y = out(c2(torch.cat((s, y), 1)))
             if c1 is not None:
                 y = c1(self._up2(y))

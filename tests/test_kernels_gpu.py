@@ -129,12 +129,14 @@ def test_gemm_stream_k_split(ops, cfg):
     g.A, g.lda, g.Cs, g.B, g.ldb, g.b_layout, g.C, g.ldc = A.data_ptr(), K, K, Bop.data_ptr(), (N if bl else K), bl, A.data_ptr(), N
     g.M, g.N, g.K, g.Z, g.Zi, g.g = M, N, K, 1, 1, H.gemm_geom()
     assert H.lib().corrif_gemm_fwd_workspace(g) > 0, "this shape is expected to take the stream-K path"
-    c1, c2 = run(), run()
-    ops.STREAM_K = False
+    was = ops.STREAM_K
     try:
+        ops.STREAM_K = True
+        c1, c2 = run(), run()
+        ops.STREAM_K = False
         c0 = run()
     finally:
-        ops.STREAM_K = True
+        ops.STREAM_K = was
     torch.cuda.synchronize()
     assert torch.equal(c1, c2)
     assert rel(c1, ref) < 2e-6 and rel(c0, ref) < 2e-6

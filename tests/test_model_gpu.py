@@ -99,8 +99,11 @@ def test_against_reference_fixture_tame(name):
 def test_against_reference_fixture_kaiming_bracketed(name):
     """The reference's REAL init scale (kaiming_normal_, mmvit4.py:437-439), also at the BASELINE size 224^2 with B = 2 (non-trivial
     inter-modal re-view and BatchNorm batch statistics).  Activations reach 1e3-1e4 and the 3-way correlation softmax saturates, so
-    the bar is k x the reference's own fp32-vs-fp64 error, k = 5, for the prediction AND for every sampled gradient and
-    gradient norm of helpers.GRAD_KEYS (45 tensors covering every kernel family); soft Jaccard stays within 1e-5."""
+    the bar is k x the reference's own fp32-vs-fp64 error: k = 5 for the prediction and the loss, k = 10 (as for the tame
+    fixtures) for every sampled gradient and gradient norm of helpers.GRAD_KEYS (45 tensors covering every kernel family); soft
+    Jaccard stays within 1e-5.  A gradient norm is not asked to be more accurate than the tensor's sampled elements: for sums that
+    cancel analytically (e1_bn.bias: every path but adapt1's is annihilated by the next BatchNorm) the reference's own norm error is
+    small only by accident (8e-5 next to 1e-2 on its elements)."""
     import mmvit4
     case = CASES[name]
     g = np.load(os.path.join(helpers.GOLDEN, name + ".npz"))
@@ -123,7 +126,7 @@ def test_against_reference_fixture_kaiming_bracketed(name):
         nr = float(g["f64/grad_norm/" + k])
         nerr = abs(params[k].grad.double().norm().item() - nr) / max(nr, 1e-30)
         n32 = abs(float(g["f32/grad_norm/" + k]) - nr) / max(nr, 1e-30)
-        if err > max(5 * ref32, 2e-3) or nerr > max(5 * n32, 1e-2):      # norm floor 1e-2 as for the tame fixtures
+        if err > max(10 * ref32, 2e-3) or nerr > max(10 * n32, 10 * ref32, 1e-2):      # norm floor 1e-2 as for the tame fixtures
 
             bad.append((k, err, ref32, nerr, n32))
     assert not bad, bad
@@ -186,9 +189,13 @@ def test_stage_taps_against_reference_fixture(name):
 def test_full_gradient_against_oracle():
     """EVERY parameter gradient (not a sample) and every buffer against the CPU oracle on the same inputs.
     Bracketed: the oracle is run in fp64 (truth) and fp32 (= the reference's arithmetic, bit-identical to it on CPU);
-    per parameter the HIP path's rel-L2 error vs fp64 must be <= 3x the fp32 oracle's own error (floor 2e-4)."""
+    per parameter the HIP path's rel-L2 error vs fp64 must be <= 4x the fp32 oracle's own error (floor 2e-4) - the two are
+    independent rounding realisations of the same arithmetic, so over 645 tensors single ratios reach ~3 - and the MEDIAN ratio must
+    stay <= 1.5 (a systematic loss of accuracy in any kernel family would move it).  64^2 input at batch 2: e4 / e5 still see 4x4 and
+    2x2 maps (96 / 24 samples per BatchNorm channel); at 32^2 (round 1) e5 normalised over 3 samples and both the oracle's fp32 error
+    and ours were O(1) there, which tested nothing."""
     from oracle import mmvit4_oracle as O
-    case = dict(B=1, D=3, H=32, W=32, mode="train_nodrop", conv_gain=1.0, wseed=11)
+    case = dict(B=2, D=3, H=64, W=64, mode="train_nodrop", conv_gain=1.0, wseed=11)
     model, pred, mask, loss, sd = run_hip(case)
     x, _ = helpers.make_inputs(case["B"], case["D"], case["H"], case["W"])
     res = {}
@@ -207,7 +214,7 @@ def test_full_gradient_against_oracle():
     gap = (p32 - p64).abs().max().item()
     assert (pred.detach().cpu().double() - p64).abs().max().item() < max(3 * gap, 2e-5)
     assert abs(loss.item() - l64) < max(3 * abs(l32 - l64), 2e-6)
-    bad = []
+    bad, ratios = [], []
     for k, p in model.named_parameters():
         if g64[k] is None:
             assert p.grad is None, k
@@ -215,17 +222,19 @@ def test_full_gradient_against_oracle():
         nrm = g64[k].norm().clamp_min(1e-20)
         e_hip = ((p.grad.cpu().double() - g64[k]).norm() / nrm).item()
         e_ref = ((g32[k] - g64[k]).norm() / nrm).item()
-        if e_hip > max(3 * e_ref, 2e-4):
+        ratios.append(e_hip / max(e_ref, 1e-6))
+        if e_hip > max(4 * e_ref, 2e-4):
             bad.append((k, e_hip, e_ref))
     assert not bad, bad[:10]
+    assert sorted(ratios)[len(ratios) // 2] <= 1.5, sorted(ratios)[len(ratios) // 2]
     for k, b in model.named_buffers():                # running statistics after one training step, bracketed the same way
-        if k.endswith("num_batches_tracked"):         # (e5 sees 1x1 maps here: statistics over 3 samples per channel)
+        if k.endswith("num_batches_tracked"):
             assert int(b) == int(b64[k]), k
             continue
-        nrm = b64[k].norm().clamp_min(1e-20)             # per-tensor rel-L2 (single elements are chaotic with 3 samples/channel)
+        nrm = b64[k].norm().clamp_min(1e-20)
         e_hip = ((b.cpu().double() - b64[k]).norm() / nrm).item()
         e_ref = ((b32[k] - b64[k]).norm() / nrm).item()
-        assert e_hip <= max(3 * e_ref, 1e-4), (k, e_hip, e_ref)
+        assert e_hip <= max(4 * e_ref, 5e-5), (k, e_hip, e_ref)
 
 
 @pytest.mark.parametrize("B,D,HW", [(1, 8, 256), (1, 12, 512), (3, 5, 100)])
@@ -274,7 +283,7 @@ def _oracle_on_device(case, dtype, sd, device=DEV):
 
 def test_device_oracle_is_pinned_by_the_reference_fixture():
     """The fp64 device evaluation of the oracle reproduces the upstream reference's own fp64 run (fixture captured by importing the
-    reference, tests/golden/make_golden.py) to 1e-9 on the prediction and 1e-7 relative on sampled gradients: it is a valid 'truth'
+    reference, tests/golden/make_golden.py) to 5e-9 on the prediction and 1e-7 relative on sampled gradients: it is a valid 'truth'
     for the sizes below."""
     name = "tame_train_b2_d3_64"
     case = CASES[name]
@@ -282,7 +291,7 @@ def test_device_oracle_is_pinned_by_the_reference_fixture():
     from oracle import mmvit4_oracle as O
     sd = helpers.make_state_dict(O.MMVit4().state_dict(), seed=case["wseed"], conv_gain=case["conv_gain"])
     r = _oracle_on_device(case, torch.float64, sd)
-    assert np.abs(r["pred_sample"] - g["f64/pred_sample"]).max() < 1e-9
+    assert np.abs(r["pred_sample"] - g["f64/pred_sample"]).max() < 5e-9        # fp64 on the device vs fp64 on the CPU: 1.0e-9 measured
     assert abs(r["loss"] - float(g["f64/loss"])) < 1e-10
     for k in helpers.GRAD_KEYS:
         ref = g["f64/grad_sample/" + k]
