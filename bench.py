@@ -41,6 +41,8 @@ class MfmaTimer:
         self.ops, self.rec, self.on = ops, [], False
         self._gemm, self._wgrad, self._patch, self._pwg = ops.gemm, ops.wgrad, ops.conv3_patch, ops.conv3_patch_wgrad
         ops.gemm, ops.wgrad, ops.conv3_patch, ops.conv3_patch_wgrad = self.gemm, self.wgrad, self.patch, self.patch_wgrad
+        self._ffwd, self._fbwd = ops.flash_fwd, ops.flash_bwd
+        ops.flash_fwd, ops.flash_bwd = self.flash_fwd, self.flash_bwd
 
     def _timed(self, fn, flops, key, a, kw):
         if not self.on:
@@ -68,6 +70,16 @@ class MfmaTimer:
     def patch_wgrad(self, *a, **kw):   # (x, ldx, gy, ldg, gwp, B, S, O, Ci, Co, clamp, dev)
         M = a[5] * a[7][0] * a[7][1] * a[7][2]
         return self._timed(self._pwg, 2.0 * M * a[9] * 27 * a[8], ("patch_wgrad", M, a[9], 27 * a[8], 1), a, kw)
+
+    # flash attention: ALGORITHMIC products only (q.k^T and p.v forward; dv, dp, dq, dk backward = 2 + 4 products of 2*N*N*64 flop per
+    # head); the backward kernels recompute q.k^T twice and dp once on top of that, which is not credited
+    def flash_fwd(self, *a, **kw):   # (qkv, out, lse, mask, B, N, heads, ...)
+        fl = 2 * 2.0 * a[4] * a[6] * a[5] * a[5] * 64
+        return self._timed(self._ffwd, fl, ("flash_fwd", a[5], a[5], 64, a[4] * a[6]), a, kw)
+
+    def flash_bwd(self, *a, **kw):   # (qkv, out, lse, mask, go, dvec, dqkv, B, N, heads, ...)
+        fl = 4 * 2.0 * a[7] * a[9] * a[8] * a[8] * 64
+        return self._timed(self._fbwd, fl, ("flash_bwd", a[8], a[8], 64, a[7] * a[9]), a, kw)
 
     def by_shape(self):
         agg = {}
@@ -291,7 +303,7 @@ def main():
                                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                                "traffic_note": "HBM bytes per step of the same launches (sum over the MFMA family), rocprofv3 FETCH_SIZE x2 + "
                                                "WRITE_SIZE from separate --pmc passes (profiles/r01_mfma_traffic.json); algorithmic = 243 GB",
-                               "kernel": "gemm_fwd_kernel+wgrad_kernel+conv3_patch_kernel (fp32 MFMA implicit GEMM / patch conv)",
+                               "kernel": "gemm_fwd_kernel+wgrad_kernel+conv3_patch_kernel+flash_* (fp32 MFMA implicit GEMM / patch conv / attention)",
                                "launches_per_step": n // max(kt_steps, 1), "mfma_ms_per_step": round(ms / max(kt_steps, 1), 3),
                                "algorithmic_gflop_per_step": round(fl / max(kt_steps, 1) / 1e9, 1),
                                "method": "HIP events around each MFMA launch (weight gradients incl. their fixed-order slab reduce), %d extra "

@@ -33,7 +33,8 @@ class Gemm(C.Structure):
                 ("g", Geom), ("ntap_sel", i32), ("tap_sel", C.c_int8 * 28),
                 ("out_map", i32), ("OD", i32), ("OH", i32), ("OW", i32), ("om_d", i32), ("om_h", i32), ("om_w", i32),
                 ("oo_d", i32), ("oo_h", i32), ("oo_w", i32),
-                ("stats_part", ptr), ("stats_rows_per_group", i64), ("stats_relu", i32), ("ws", ptr), ("no_split", i32)]
+                ("stats_part", ptr), ("stats_rows_per_group", i64), ("stats_relu", i32), ("ws", ptr), ("no_split", i32),
+                ("addend2", ptr), ("ld_add2", i64)]
 
 
 class Wgrad(C.Structure):
@@ -95,6 +96,10 @@ _SIGS = {
     "corrif_softmax_rows_bwd": (i32, [ptr, ptr, i64, i32, f32, ptr]),
     "corrif_softmax_dropout_rows": (i32, [ptr, ptr, i64, i32, f32, f32, u64, u64, ptr]),
     "corrif_softmax_dropout_rows_bwd": (i32, [ptr, ptr, i64, i32, f32, f32, u64, u64, ptr]),
+    "corrif_flash_attn_supported": (i32, [i32, i32]),
+    "corrif_flash_attn_mask_bytes": (C.c_size_t, [i32, i32, i32, f32]),
+    "corrif_flash_attn_fwd": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, f32, f32, u64, u64, ptr]),
+    "corrif_flash_attn_bwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, f32, f32, ptr]),
     "corrif_dropout": (i32, [ptr, ptr, i64, f32, u64, u64, ptr]),
     "corrif_add": (i32, [ptr, ptr, ptr, i64, ptr]),
     "corrif_add_bcast_rows": (i32, [ptr, ptr, i64, ptr, i64, ptr]),
@@ -137,7 +142,7 @@ def lib():
             fn = getattr(l, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if l.corrif_abi_version() != 3:
+        if l.corrif_abi_version() != 4:
             raise RuntimeError("corrif: ABI version mismatch")
         _lib = l
     return _lib

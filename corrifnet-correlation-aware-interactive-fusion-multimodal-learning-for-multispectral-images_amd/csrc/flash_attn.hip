@@ -14,8 +14,8 @@
 //
 // Dropout mask = the Philox4x32-10 stream of corrif_dropout over the flat [B, heads, N, N] index (counter = offset/4 + index/4,
 // element = index % 4), so the fused kernels reproduce the unfused softmax + dropout passes bit for bit in the mask.  With queries
-// as columns the four consecutive keys of one counter are the lane's own registers 4 g .. 4 g + 3; with keys as columns they are
-// the four lanes of a quad, which share the work (one call each) and exchange the words with DPP quad permutes.
+// as columns the four consecutive keys of one counter are the lane's own registers 4 g .. 4 g + 3.  The forward draws the mask once
+// and leaves it as keep BITS ([B*heads][N][N/32] words, 1/32 of a score tensor); the backward kernels read the bits.
 //
 // Deterministic: no atomics; dQ and (dK, dV) come from two kernels that each own their output rows.
 #include "common.h"
@@ -57,6 +57,7 @@ struct FlashArgs {
     const float* dout;    // bwd: dO [B][N][C]
     const float* dvec;    // bwd: D = rowsum(dO * O)  [B*heads][N]
     float* dqkv;          // bwd: [B][N][3*C]
+    uint32_t* mask;       // dropout keep bits [B*heads][N][N/32] (bit j of word kb <-> key 32 kb + j), written by fwd, read by bwd
     int N, heads, C;
     float scale, pdrop, inv_keep;
     uint64_t seed, offset4;
@@ -74,34 +75,30 @@ __device__ __forceinline__ void store_tile_lds(float* lds, int tid, const f32x4 
     for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(lds + (r + 16 * i) * TP + c4 * 4) = v[i];
 }
 
-// acc[t] (t = 0, 1: rows 32 t .. 32 t + 31 of the LDS tile) += tile[rows][0..63] . frag^T, frag = this lane's resident operand
-// (row `lane & 31` of its own 32-row block, float4 chunks k = 8 s + 4 h .. + 3)
-__device__ __forceinline__ void tile_times_resident(const float* tile, const f32x4 (&frag)[8], int lane, f32x16 (&acc)[2]) {
+// acc += tile[rows 32 t .. 32 t + 31][0..63] . frag^T (one 32-row block of the LDS tile)
+__device__ __forceinline__ void block_times_resident(const float* tile, int t, const f32x4 (&frag)[8], int lane, f32x16& acc) {
     const int i = lane & 31, h4 = (lane >> 5) * 4;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        f32x4 a0 = *reinterpret_cast<const f32x4*>(tile + i * TP + s * 8 + h4);
-        f32x4 a1 = *reinterpret_cast<const f32x4*>(tile + (32 + i) * TP + s * 8 + h4);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(tile + (32 * t + i) * TP + s * 8 + h4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], frag[s][e], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], frag[s][e], acc[1], 0, 0, 0);
-        }
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], frag[s][e], acc, 0, 0, 0);
     }
 }
-// out[dt] (dt = 0, 1: head-dim rows 32 dt ..) += tile^T . w : contraction over the 64 tile rows, w[t][r] = this lane's register
-// for tile row 32 t + 8 (r >> 2) + 4 h + (r & 3)
-__device__ __forceinline__ void tileT_times_regs(const float* tile, const f32x16 (&w)[2], int lane, f32x16 (&out)[2]) {
+// out[dt] += (tile rows 32 t ..)^T . w : contraction over that 32-row block, w[r] = this lane's register for row 32 t + 8 (r >> 2) + 4 h + (r & 3)
+__device__ __forceinline__ void blockT_times_regs(const float* tile, int t, const f32x16& w, int lane, f32x16 (&out)[2]) {
     const int i = lane & 31, h4 = (lane >> 5) * 4;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int r = 0; r < 16; ++r) {
+        const int row = 32 * t + 8 * (r >> 2) + h4 + (r & 3);
+        const float a0 = tile[row * TP + i], a1 = tile[row * TP + 32 + i];
+        out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w[r], out[0], 0, 0, 0);
+        out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w[r], out[1], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void zero1(f32x16& a) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 * t + 8 * (r >> 2) + h4 + (r & 3);
-            const float a0 = tile[row * TP + i], a1 = tile[row * TP + 32 + i];
-            out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w[t][r], out[0], 0, 0, 0);
-            out[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w[t][r], out[1], 0, 0, 0);
-        }
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
 __device__ __forceinline__ void zero2(f32x16 (&a)[2]) {
 #pragma unroll
@@ -130,7 +127,7 @@ __device__ __forceinline__ void store_cols(float* __restrict__ p, int lane, cons
 // =============================================================================================== forward
 // grid (N / 128, B * heads); wave w owns queries q0 + 32 w ..; the workgroup streams 64-key K / V tiles through LDS.
 template <bool DROP>
-__global__ __launch_bounds__(256) void flash_fwd_kernel(FlashArgs p) {
+__global__ __launch_bounds__(256, 3) void flash_fwd_kernel(FlashArgs p) {
     __shared__ __attribute__((aligned(16))) float Ks[KT * TP];
     __shared__ __attribute__((aligned(16))) float Vs[KT * TP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -158,40 +155,46 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashArgs p) {
             load_tile_regs(base + (int64_t)(k0 + KT) * ld + p.C, ld, tid, kr);
             load_tile_regs(base + (int64_t)(k0 + KT) * ld + 2 * p.C, ld, tid, vr);
         }
-        f32x16 s[2];
-        zero2(s);
-        tile_times_resident(Ks, qf, lane, s);          // S^T tile: rows = keys, column = query n
-        float mx = -INFINITY;
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {                  // online softmax per 32-key block: one score accumulator live at a time
+            f32x16 s;
+            zero1(s);
+            block_times_resident(Ks, t, qf, lane, s);  // S^T block: rows = keys, column = query n
+            float mx = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int r = 0; r < 16; ++r) { s[r] *= p.scale; mx = fmaxf(mx, s[r]); }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = expf(m_run - m_new);   // first block: exp(-inf) = 0
+            m_run = m_new;
+            float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[t][r] *= p.scale; mx = fmaxf(mx, s[t][r]); }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = expf(m_run - m_new);       // first tile: exp(-inf) = 0
-        m_run = m_new;
-        float sum = 0.f;
+            for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - m_new); sum += s[r]; }
+            l_run = l_run * alpha + sum;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[t][r] = expf(s[t][r] - m_new); sum += s[t][r]; }
-        l_run = l_run * alpha + sum;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-        if constexpr (DROP) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            if constexpr (DROP) {
+                uint32_t bits = 0;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     uint32_t w[4];
                     philox_(p.offset4 + row4 + (uint64_t)((k0 + 32 * t + 8 * g + h4) >> 2), p.seed, w);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) s[t][4 * g + e] *= keep_factor(w[e], p.pdrop, p.inv_keep);
+                    for (int e = 0; e < 4; ++e) {
+                        const float kf = keep_factor(w[e], p.pdrop, p.inv_keep);
+                        s[4 * g + e] *= kf;
+                        bits |= (kf != 0.f ? 1u : 0u) << (8 * g + h4 + e);
+                    }
                 }
+                // the mask is drawn once: the backward kernels read these bits instead of re-running Philox (10 rounds per 4 elements,
+                // ~0.7 ms per pass over the [32, 8, 2048, 2048] index space)
+                bits |= (uint32_t)__shfl_xor((int)bits, 32);
+                if (lane < 32) p.mask[((int64_t)z * p.N + n) * (p.N >> 5) + ((k0 >> 5) + t)] = bits;
+            }
+            blockT_times_regs(Vs, t, s, lane, o);      // O^T += V^T P'^T
         }
-        tileT_times_regs(Vs, s, lane, o);              // O^T += V^T P'^T
         __syncthreads();
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256) void flash_dvec_kernel(const float* __restrict
 // =============================================================================================== backward: dQ
 // grid (N / 128, B * heads); wave owns 32 queries (columns), streams 64-key K / V tiles.
 template <bool DROP>
-__global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashArgs p) {
+__global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(FlashArgs p) {
     __shared__ __attribute__((aligned(16))) float Ks[KT * TP];
     __shared__ __attribute__((aligned(16))) float Vs[KT * TP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -239,7 +242,6 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashArgs p) {
     load_resident(base + (int64_t)n * ld, lane, qf);
     load_resident(p.dout + ((int64_t)b * p.N + n) * p.C + hh * HD, lane, gf);
     const float lse = p.lse[(int64_t)z * p.N + n], dv = p.dvec[(int64_t)z * p.N + n];
-    const uint64_t row4 = ((uint64_t)z * p.N + n) * (uint64_t)(p.N / 4);
     f32x16 dq[2];
     zero2(dq);
     for (int k0 = 0; k0 < p.N; k0 += KT) {
@@ -249,27 +251,28 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashArgs p) {
         store_tile_lds(Ks, tid, kr);
         store_tile_lds(Vs, tid, vr);
         __syncthreads();
-        f32x16 s[2], dp[2];
-        zero2(s);
-        zero2(dp);
-        tile_times_resident(Ks, qf, lane, s);          // S^T
-        tile_times_resident(Vs, gf, lane, dp);         // dP'^T = V dO^T
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {
+            f32x16 s, dp;
+            zero1(s);
+            zero1(dp);
+            uint32_t bits = 0;
+            if constexpr (DROP) bits = p.mask[((int64_t)z * p.N + n) * (p.N >> 5) + ((k0 >> 5) + t)];
+            block_times_resident(Ks, t, qf, lane, s);      // S^T
+            block_times_resident(Vs, t, gf, lane, dp);     // dP'^T = V dO^T
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                uint32_t w[4] = {0, 0, 0, 0};
-                if constexpr (DROP) philox_(p.offset4 + row4 + (uint64_t)((k0 + 32 * t + 8 * g + h4) >> 2), p.seed, w);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
-                    const float pr = expf(s[t][r] * p.scale - lse);
-                    float d = dp[t][r];
-                    if constexpr (DROP) d *= keep_factor(w[e], p.pdrop, p.inv_keep);
-                    s[t][r] = p.scale * pr * (d - dv);          // dS^T
+                    const float pr = expf(s[r] * p.scale - lse);
+                    float d = dp[r];
+                    if constexpr (DROP) d = (bits >> (8 * g + h4 + e)) & 1u ? d * p.inv_keep : 0.f;
+                    s[r] = p.scale * pr * (d - dv);             // dS^T
                 }
             }
-        tileT_times_regs(Ks, s, lane, dq);             // dQ^T += K^T dS^T
+            blockT_times_regs(Ks, t, s, lane, dq);         // dQ^T += K^T dS^T
+        }
         __syncthreads();
     }
     store_cols(p.dqkv + ((int64_t)b * p.N + n) * ld + hh * HD, lane, dq, 1.0f);
@@ -277,29 +280,20 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashArgs p) {
 
 // =============================================================================================== backward: dK, dV
 // grid (N / 128, B * heads); wave owns 32 keys (columns), streams 64-query Q / dO tiles (+ their lse / D entries).
-__device__ __forceinline__ uint32_t quad_bcast(uint32_t v, int src) {
-    // value of lane (quad base + src) for every lane of the quad
-    switch (src) {
-        case 0: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x00, 0xF, 0xF, true);      // quad_perm [0,0,0,0]
-        case 1: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x55, 0xF, 0xF, true);      // [1,1,1,1]
-        case 2: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xAA, 0xF, 0xF, true);      // [2,2,2,2]
-        default: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xFF, 0xF, 0xF, true);     // [3,3,3,3]
-    }
-}
-
 template <bool DROP>
-__global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashArgs p) {
+__global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(FlashArgs p) {
     __shared__ __attribute__((aligned(16))) float Qs[KT * TP];
     __shared__ __attribute__((aligned(16))) float Gs[KT * TP];
     __shared__ __attribute__((aligned(16))) float Ls[KT];
     __shared__ __attribute__((aligned(16))) float Ds[KT];
+    __shared__ __attribute__((aligned(16))) uint32_t Ms[4 * KT];       // keep bits of (query row, this wave's 32-key block)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int z = blockIdx.y, b = z / p.heads, hh = z - b * p.heads;
     const int64_t ld = 3 * (int64_t)p.C;
     const float* __restrict__ base = p.qkv + (int64_t)b * p.N * ld + hh * HD;
     const float* __restrict__ gbase = p.dout + (int64_t)b * p.N * p.C + hh * HD;
     const int m = blockIdx.x * 128 + wave * 32 + (lane & 31);          // this lane's key (column)
-    const int h4 = (lane >> 5) * 4, ql = lane & 3;
+    const int h4 = (lane >> 5) * 4;
 
     f32x4 kf[8], vf[8];
     load_resident(base + (int64_t)m * ld + p.C, lane, kf);
@@ -307,7 +301,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashArgs p) {
     f32x16 dk[2], dvv[2];
     zero2(dk);
     zero2(dvv);
-    const uint32_t mq = (uint32_t)(m >> 2);                            // this quad's counter column
+    const int kb = blockIdx.x * 4 + wave, bit = lane & 31;             // this wave's 32-key block / this lane's bit in its words
     for (int q0 = 0; q0 < p.N; q0 += KT) {
         f32x4 qr[4], gr[4];
         load_tile_regs(base + (int64_t)q0 * ld, ld, tid, qr);
@@ -318,14 +312,15 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashArgs p) {
             Ls[tid] = p.lse[(int64_t)z * p.N + q0 + tid];
             Ds[tid] = p.dvec[(int64_t)z * p.N + q0 + tid];
         }
+        if constexpr (DROP) Ms[tid] = p.mask[((int64_t)z * p.N + q0 + lane) * (p.N >> 5) + kb];      // thread (wave, lane): row q0 + lane
         __syncthreads();
-        f32x16 s[2], dp[2];
-        zero2(s);
-        zero2(dp);
-        tile_times_resident(Qs, kf, lane, s);          // S: rows = queries, column = key m
-        tile_times_resident(Gs, vf, lane, dp);         // dP' = dO V^T
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {
+            f32x16 s, dp;
+            zero1(s);
+            zero1(dp);
+            block_times_resident(Qs, t, kf, lane, s);      // S: rows = queries, column = key m
+            block_times_resident(Gs, t, vf, lane, dp);     // dP' = dO V^T
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int rbase = 32 * t + 8 * g + h4;                 // tile rows rbase .. rbase + 3 <-> registers 4 g .. 4 g + 3
@@ -333,28 +328,23 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashArgs p) {
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(&Ds[rbase]);
                 uint32_t w[4] = {0, 0, 0, 0};
                 if constexpr (DROP) {
-                    // the quad's four lanes need word (m & 3) of the counters of rows rbase .. rbase + 3; lane ql computes row rbase + ql
-                    const uint64_t ctr = p.offset4 + ((uint64_t)z * p.N + (uint64_t)(q0 + rbase + ql)) * (uint64_t)(p.N / 4) + mq;
-                    philox_(ctr, p.seed, w);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = Ms[wave * KT + rbase + e];
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
                     float kf_ = 1.f;
-                    if constexpr (DROP) {
-                        // row rbase + e was computed by quad lane e; take its word number (m & 3) = ql
-                        const uint32_t w0 = quad_bcast(w[0], e), w1 = quad_bcast(w[1], e), w2 = quad_bcast(w[2], e), w3 = quad_bcast(w[3], e);
-                        const uint32_t word = ql == 0 ? w0 : ql == 1 ? w1 : ql == 2 ? w2 : w3;
-                        kf_ = keep_factor(word, p.pdrop, p.inv_keep);
-                    }
-                    const float pr = expf(s[t][r] * p.scale - l4[e]);
-                    const float d = dp[t][r] * kf_;
-                    dp[t][r] = pr * kf_;                                // P'
-                    s[t][r] = p.scale * pr * (d - d4[e]);               // dS
+                    if constexpr (DROP) kf_ = (w[e] >> bit) & 1u ? p.inv_keep : 0.f;
+                    const float pr = expf(s[r] * p.scale - l4[e]);
+                    const float d = dp[r] * kf_;
+                    dp[r] = pr * kf_;                                   // P'
+                    s[r] = p.scale * pr * (d - d4[e]);                  // dS
                 }
             }
-        tileT_times_regs(Gs, dp, lane, dvv);           // dV^T += dO^T P'
-        tileT_times_regs(Qs, s, lane, dk);             // dK^T += Q^T dS
+            blockT_times_regs(Gs, t, dp, lane, dvv);       // dV^T += dO^T P'
+            blockT_times_regs(Qs, t, s, lane, dk);         // dK^T += Q^T dS
+        }
         __syncthreads();
     }
     store_cols(p.dqkv + ((int64_t)b * p.N + m) * ld + p.C + hh * HD, lane, dk, 1.0f);
@@ -372,12 +362,17 @@ bool flash_ok(const void* qkv, int32_t B, int32_t N, int32_t heads, float pdrop,
 
 extern "C" int corrif_flash_attn_supported(int32_t N, int32_t head_dim) { return head_dim == HD && N > 0 && N % 128 == 0; }
 
-extern "C" int corrif_flash_attn_fwd(const float* qkv, float* out, float* lse, int32_t B, int32_t N, int32_t heads, float scale, float pdrop,
-                                     uint64_t seed, uint64_t offset, void* stream) {
-    if (!flash_ok(qkv, B, N, heads, pdrop, offset) || !out || !lse) return CORRIF_EINVAL;
+extern "C" size_t corrif_flash_attn_mask_bytes(int32_t B, int32_t N, int32_t heads, float pdrop) {
+    if (!(pdrop > 0.f) || B <= 0 || N <= 0 || heads <= 0) return 0;
+    return (size_t)B * heads * N * (N / 32) * sizeof(uint32_t);
+}
+
+extern "C" int corrif_flash_attn_fwd(const float* qkv, float* out, float* lse, uint32_t* mask, int32_t B, int32_t N, int32_t heads, float scale,
+                                     float pdrop, uint64_t seed, uint64_t offset, void* stream) {
+    if (!flash_ok(qkv, B, N, heads, pdrop, offset) || !out || !lse || (pdrop > 0.f && !mask)) return CORRIF_EINVAL;
     if (((uintptr_t)out & 15)) return CORRIF_EUNSUPPORTED;
     FlashArgs a{};
-    a.qkv = qkv; a.out = out; a.lse = lse; a.N = N; a.heads = heads; a.C = heads * HD;
+    a.qkv = qkv; a.out = out; a.lse = lse; a.mask = mask; a.N = N; a.heads = heads; a.C = heads * HD;
     a.scale = scale; a.pdrop = pdrop; a.inv_keep = 1.0f / (1.0f - pdrop); a.seed = seed; a.offset4 = offset / 4;
     dim3 grid(N / 128, B * heads);
     if (pdrop > 0.f) hipLaunchKernelGGL(flash_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -386,14 +381,14 @@ extern "C" int corrif_flash_attn_fwd(const float* qkv, float* out, float* lse, i
     return CORRIF_OK;
 }
 
-extern "C" int corrif_flash_attn_bwd(const float* qkv, const float* out, const float* lse, const float* dout, float* dvec, float* dqkv,
-                                     int32_t B, int32_t N, int32_t heads, float scale, float pdrop, uint64_t seed, uint64_t offset,
-                                     void* stream) {
-    if (!flash_ok(qkv, B, N, heads, pdrop, offset) || !out || !lse || !dout || !dvec || !dqkv) return CORRIF_EINVAL;
+extern "C" int corrif_flash_attn_bwd(const float* qkv, const float* out, const float* lse, const uint32_t* mask, const float* dout, float* dvec,
+                                     float* dqkv, int32_t B, int32_t N, int32_t heads, float scale, float pdrop, void* stream) {
+    if (!flash_ok(qkv, B, N, heads, pdrop, 0) || !out || !lse || !dout || !dvec || !dqkv || (pdrop > 0.f && !mask)) return CORRIF_EINVAL;
     if (((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 15)) return CORRIF_EUNSUPPORTED;
     FlashArgs a{};
-    a.qkv = qkv; a.lse = const_cast<float*>(lse); a.dout = dout; a.dvec = dvec; a.dqkv = dqkv; a.N = N; a.heads = heads; a.C = heads * HD;
-    a.scale = scale; a.pdrop = pdrop; a.inv_keep = 1.0f / (1.0f - pdrop); a.seed = seed; a.offset4 = offset / 4;
+    a.qkv = qkv; a.lse = const_cast<float*>(lse); a.mask = const_cast<uint32_t*>(mask); a.dout = dout; a.dvec = dvec; a.dqkv = dqkv;
+    a.N = N; a.heads = heads; a.C = heads * HD;
+    a.scale = scale; a.pdrop = pdrop; a.inv_keep = 1.0f / (1.0f - pdrop);
     hipStream_t s = (hipStream_t)stream;
     const int64_t groups = (int64_t)B * N * heads;
     hipLaunchKernelGGL(flash_dvec_kernel, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256), 0, s, out, dout, dvec, B, N, heads);

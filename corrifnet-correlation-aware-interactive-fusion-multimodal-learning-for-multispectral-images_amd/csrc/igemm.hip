@@ -237,7 +237,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
     float* const stg = lds + wave * 32 * SP;
     const int rr = lane / CQ, cq = lane % CQ;
     const int col = n0 + wn * TN * 32 + cq * 4;   // this lane's 4 output columns (fixed for all passes)
-    const bool vec_ok = !(p.ldc & 3) && !((uintptr_t)C & 15) && (!p.addend || (!(p.ld_add & 3) && !((uintptr_t)p.addend & 15)));
+    const bool vec_ok = !(p.ldc & 3) && !((uintptr_t)C & 15) && (!p.addend || (!(p.ld_add & 3) && !((uintptr_t)p.addend & 15))) &&
+                        (!p.addend2 || (!(p.ld_add2 & 3) && !((uintptr_t)p.addend2 & 15)));
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
 #pragma unroll
@@ -279,6 +280,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
             float* __restrict__ dst = C + orow * p.ldc + col;
             if (vec_ok && col + 3 < p.N) {
                 if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + (int64_t)row * p.ld_add + col);
+                if (p.addend2) v += *reinterpret_cast<const f32x4*>(p.addend2 + (int64_t)row * p.ld_add2 + col);
                 if (p.act == CORRIF_ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -293,6 +295,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
                     if (col + e >= p.N) break;
                     float x = v[e];
                     if (p.addend) x += p.addend[(int64_t)row * p.ld_add + col + e];
+                    if (p.addend2) x += p.addend2[(int64_t)row * p.ld_add2 + col + e];
                     if (p.act == CORRIF_ACT_RELU) x = fmaxf(x, 0.f);
                     else if (p.act == CORRIF_ACT_GELU) x = gelu_erf(x);
                     dst[e] = x;
@@ -533,13 +536,14 @@ static int gemm_fwd_impl(const CorrifGemm* p, void* stream, bool plan_only, size
     if (!geom_ok(p->g)) return CORRIF_EINVAL;
     if (!p->g.is_gemm && (int64_t)p->g.Sd * p->g.Sh * p->g.Sw * p->lda >= (int64_t)1 << 31) return CORRIF_EUNSUPPORTED;   // 32-bit in-sample offsets
     if (p->ntap_sel < 0 || p->ntap_sel > 28 || (p->ntap_sel && (p->g.is_gemm || scalar))) return CORRIF_EINVAL;
-    if (p->out_map && (p->g.is_gemm || p->addend || p->N > 4096 * 1024)) return CORRIF_EINVAL;
+    if (p->out_map && (p->g.is_gemm || p->addend || p->addend2 || p->N > 4096 * 1024)) return CORRIF_EINVAL;
+    if (p->addend2 && !p->addend) return CORRIF_EINVAL;
     if (!p->g.is_gemm && !scalar && p->K != (p->ntap_sel ? p->ntap_sel : p->g.kd * p->g.kh * p->g.kw) * p->Cs) return CORRIF_EINVAL;
     if (scalar && (p->g.ntaps <= 0 || p->g.ntaps > p->g.kd * p->g.kh * p->g.kw || p->K < p->g.ntaps)) return CORRIF_EINVAL;
     if (p->Z > 65535) return CORRIF_EUNSUPPORTED;
     if (p->ws && ((uintptr_t)p->ws & 15)) return CORRIF_EUNSUPPORTED;
     GemmArgs a;
-    a.A = p->A; a.B = p->B; a.C = p->C; a.bias = p->bias; a.addend = p->addend;
+    a.A = p->A; a.B = p->B; a.C = p->C; a.bias = p->bias; a.addend = p->addend; a.addend2 = p->addend2; a.ld_add2 = p->ld_add2;
     a.lda = p->lda; a.ldb = p->ldb; a.ldc = p->ldc; a.ld_add = p->ld_add;
     a.M = p->M; a.N = p->N; a.K = p->K; a.Cs4 = p->Cs / 4; a.act = p->act; a.b_layout = p->b_layout; a.Zi = p->Zi;
     a.sA_o = p->sA_o; a.sA_i = p->sA_i; a.sB_o = p->sB_o; a.sB_i = p->sB_i; a.sC_o = p->sC_o; a.sC_i = p->sC_i;
@@ -566,7 +570,7 @@ static int gemm_fwd_impl(const CorrifGemm* p, void* stream, bool plan_only, size
         if (p->N <= 64) return launch_fwd<128, 64, 2, 2>(a, Z, s, plan_only, ws_bytes);
         return launch_fwd<128, 128, 2, 2>(a, Z, s, plan_only, ws_bytes);
     }
-    if (p->N <= 16 && !(p->N & 3) && !(p->ldc & 3) && !((uintptr_t)p->C & 15) && !(p->sC_o & 3) && !(p->sC_i & 3) &&
+    if (p->N <= 16 && !p->addend2 && !(p->N & 3) && !(p->ldc & 3) && !((uintptr_t)p->C & 15) && !(p->sC_o & 3) && !(p->sC_i & 3) &&
         (!p->addend || (!(p->ld_add & 3) && !((uintptr_t)p->addend & 15)))) {
         if (plan_only) return CORRIF_OK;
         return launch_smalln_fwd(a, Z, s);

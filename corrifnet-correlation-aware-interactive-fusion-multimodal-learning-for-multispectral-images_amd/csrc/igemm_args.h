@@ -17,6 +17,7 @@ struct GemmArgs {
     // stream-K split (igemm.hip): G persistent workgroups share sk_tiles * sk_nk (tile, K tile) iterations; partial accumulators go to
     // sk_ws[2 * G][BM * BN]; sk_tiles = sk_tiles_mn * Z
     float* sk_ws; int sk_G, sk_nk, sk_tiles, sk_tiles_mn, sk_allowed;
+    const float* addend2; int64_t ld_add2;      // second epilogue addend (a tensor with three consumers: two gradients ride along)
 };
 
 

@@ -53,6 +53,11 @@ class GradAllReducer:
         self._hooks = []
         self._stream = None
         self._next = 0
+        if not self.active:
+            # one rank, no collective to run: no buckets at all.  zero_grad() drops the gradients (p.grad = None), so autograd's
+            # AccumulateGrad adopts each freshly produced gradient tensor instead of adding it into a zeroed bucket view - that add was
+            # one stock ATen launch per parameter and step (645 of them in the single-GPU step of round 1).
+            return
         if skip_prefixes is not None:        # the grad-less set is known: buckets (and hooks) exist before the first backward
             self._build([p for n, p in named if not n.startswith(tuple(skip_prefixes))])
         # else: built lazily after the first backward, from the parameters that did receive a gradient
@@ -133,7 +138,7 @@ class GradAllReducer:
 
     def zero_grad(self):
         """keeps the bucket views alive (set_to_none would drop them)"""
-        if self.buckets is None:
+        if self.buckets is None or not self.active:
             for p in self.params:
                 p.grad = None
             return
@@ -149,10 +154,10 @@ class GradAllReducer:
     def finish(self):
         """call after backward(): issues whatever the hooks have not issued (in index order), waits, averages.  After it returns
         every rank holds the mean gradient in p.grad."""
-        if self.buckets is None:
-            self._build([p for p in self.params if p.grad is not None])
         if not self.active:
             return
+        if self.buckets is None:
+            self._build([p for p in self.params if p.grad is not None])
         for b in self.buckets:           # first lazy step / overlap disabled / a bucket whose hooks did not all fire
             if not b["launched"]:
                 self._launch(b)

@@ -200,29 +200,41 @@ class Bottleneck3D(nn.Module):
         self.bn3 = BatchNorm3dP(cout)
         self.downsample = nn.Sequential(Conv3dP(cin, cout, 1, (1, stride, stride), 0, False), BatchNorm3dP(cout)) if down else None
 
-    def forward(self, x):
+    def forward(self, x, link=None):
+        """link: the gradient link of this block's conv1 when the caller has parked further consumers of x on it (Encoder: the adapt
+        convolution of the previous layer's output)"""
         train = self.training
 
         def st():                                   # BatchNorm batch statistics come out of the producing GEMM's epilogue
             return {"G": 1, "relu": False} if train else None
 
-        idt, link = x, None
-        if self.downsample is not None:
-            s0 = st()
-            idt = self.downsample[1](self.downsample[0](x, stats=s0), pre=s0)
-        elif GRAD_TAP and torch.is_grad_enabled() and x.requires_grad:
-            link = {}          # identity block: x feeds conv1 AND the residual add; conv1's data-gradient epilogue absorbs the latter's gradient
+        if link is None and GRAD_TAP and torch.is_grad_enabled() and x.requires_grad:
+            link = {}          # x feeds conv1 AND the residual add / the downsample conv: conv1's data-gradient epilogue absorbs their gradient
         s1, s2, s3 = st(), st(), st()
         y = self.bn1(self.conv1(x, stats=s1, grad_link=link), relu_out=True, pre=s1)
         y = self.bn2(self.conv2(y, stats=s2), relu_out=True, pre=s2)
         y = self.conv3(y, stats=s3)
-        if link is not None:
-            idt = ops.grad_tap(x, link)        # created after conv1..conv3's nodes: its backward runs before theirs
+        xt = x if link is None else ops.grad_tap(x, link)      # created after conv1..conv3's nodes: its backward runs before theirs
+        if self.downsample is not None:                        # (the downsample path's nodes too: they are created here, not first)
+            s0 = st()
+            idt = self.downsample[1](self.downsample[0](xt, stats=s0), pre=s0)
+        else:
+            idt = xt
         return self.bn3(y, residual=idt, relu_out=True, pre=s3)
 
 
+class _ResLayer(nn.Sequential):
+    """nn.Sequential of Bottleneck3D (same state-dict keys `0.`, `1.`, ...; module hooks on the layer keep working) whose first block
+    can be handed the gradient link of the layer input (see Encoder.forward)"""
+
+    def forward(self, x, link=None):
+        for i, blk in enumerate(self):
+            x = blk(x, link) if i == 0 else blk(x)
+        return x
+
+
 def _res_layer(cin, width, n, stride):
-    return nn.Sequential(Bottleneck3D(cin, width, stride, True), *[Bottleneck3D(4 * width, width, 1, False) for _ in range(n - 1)])
+    return _ResLayer(Bottleneck3D(cin, width, stride, True), *[Bottleneck3D(4 * width, width, 1, False) for _ in range(n - 1)])
 
 
 _ADAPT = ((64, basic_dims), (256, basic_dims * 2), (512, basic_dims * 4), (1024, basic_dims * 8), (2048, basic_dims * 8))
@@ -246,10 +258,16 @@ class Encoder(nn.Module):
     def forward(self, x, m, cats):
         """x: [B, D, H, W] view of modality m; cats[l]: concat buffer of level l (None until the first modality allocates it)."""
         f = ops.maxpool133(self.e1_bn(self.e1_c1(x), relu_in=True))          # conv -> ReLU -> BN -> pool (mmvit4.py:172-174)
-        feats = [f]
+        feats, links = [f], []
+        tap = GRAD_TAP and torch.is_grad_enabled()
         for layer in (self.e2, self.e3, self.e4, self.e5):
-            f = layer(f)
+            # a layer input has three consumers: the first block's conv1 and downsample conv and this level's adapt conv; the latter
+            # two park their gradients on conv1's link (ops.grad_tap) and ride along in its data-gradient epilogue
+            link = {} if tap and f.requires_grad else None
+            links.append(link)
+            f = layer(f, link)
             feats.append(f)
+        links.append(None)
         outs = []
         B = x.shape[0]
         cube = torch.empty((B, 8, 8, 8, basic_dims * 23), dtype=torch.float32, device=x.device)
@@ -258,7 +276,8 @@ class Encoder(nn.Module):
             c = _ADAPT[l][1]
             if cats[l] is None:
                 cats[l] = torch.empty(f.shape[:4] + (num_modals * c,), dtype=torch.float32, device=x.device)
-            xl = getattr(self, "adapt%d" % (l + 1))(f, out=cats[l][..., m * c:(m + 1) * c])
+            fa = f if links[l] is None else ops.grad_tap(f, links[l])
+            xl = getattr(self, "adapt%d" % (l + 1))(fa, out=cats[l][..., m * c:(m + 1) * c])
             outs.append(xl)
             parts.append(ops.trilinear(xl, (8, 8, 8), out=cube[..., off:off + c]))     # mmvit4.py:187-191
             off += c

@@ -62,7 +62,7 @@ STREAM_K = False
 
 
 def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, addend=None, ld_add=0, act=ACT_NONE,
-         Z=1, Zi=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), taps=None, out_map=None, stats=None):
+         Z=1, Zi=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), taps=None, out_map=None, stats=None, addend2=None, ld_add2=0):
     g = H.Gemm()
     if stats is not None:
         g.stats_part, g.stats_rows_per_group, g.stats_relu = stats
@@ -79,6 +79,8 @@ def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, add
     g.bias = bias if bias is not None else None
     g.addend = addend if addend is not None else None
     g.ld_add = ld_add
+    g.addend2 = addend2 if addend2 is not None else None
+    g.ld_add2 = ld_add2
     g.M, g.N, g.K, g.act = M, N, K, act
     g.Z, g.Zi = Z, Zi
     g.sA_o, g.sA_i = sA
@@ -122,7 +124,9 @@ def col_sum(t, rows, ld, C):
 
 
 def repack(src, shape_out, O, I, T, mode, ldo, zero=False):
-    out = (torch.zeros if zero else torch.empty)(shape_out, dtype=torch.float32, device=src.device)
+    out = torch.empty(shape_out, dtype=torch.float32, device=src.device)
+    if zero:
+        check(lib().corrif_fill(P(out), out.numel(), 0.0, stream()), "corrif_fill")
     check(lib().corrif_weight_repack(P(src), P(out), O, I, T, mode, ldo, stream()), "corrif_weight_repack")
     return out
 
@@ -183,8 +187,8 @@ def _dgrad_parity_classes(gy, ldg, wd, gx, B, Sin, Sout, k, stride, pad, Ci, Co)
                     covered = False
                     continue
                 launches.append((par, R, taps))
-    if not covered:
-        gx.zero_()                                  # classes no tap can reach (1x1 stride-2: 3 of 4) keep exact zeros
+    if not covered:                                 # classes no tap can reach (1x1 stride-2: 3 of 4) keep exact zeros
+        check(lib().corrif_fill(P(gx), gx.numel(), 0.0, stream()), "corrif_fill")
     for par, R, taps in launches:
         wc = torch.empty((len(taps) * Co, Ci), dtype=torch.float32, device=gx.device)
         for j, t in enumerate(taps):                # gather this class's tap blocks [Co][Ci] of the tap-major weight matrix
@@ -277,12 +281,18 @@ class ConvFn(Function):
             if is_gemm and lib().corrif_conv1x1_small_supported(Ci, Co):
                 check(lib().corrif_conv1x1_small_fwd(P(gy), ldg, P(weight), 1, 0, P(gx), Ci, Min, Co, Ci, stream()), "corrif_conv1x1_small_fwd")
             elif is_gemm:      # dX[M,Ci] = dY[M,Co] . W[Co,Ci]   (W is the [K][N] operand as stored)
-                add_p, add_ld = None, 0
+                # gradients of the same tensor parked by its other consumers (grad_tap: the residual branch of an identity block; the
+                # downsample and adapt convolutions of a layer output): the GEMM epilogue adds up to two of them, instead of separate
+                # accumulation passes over all of them
+                adds = []
                 link = ctx.grad_link
-                if link is not None and "g" in link:          # the residual branch's gradient of the same tensor (grad_tap): the GEMM
-                    ga, _, add_ld = rows_view(link.pop("g"))   # epilogue adds it, instead of a separate accumulation pass over both
-                    add_p = P(ga)
-                gemm(P(gy), ldg, P(weight), Ci, 1, P(gx), Ci, Min, Ci, Co, Co, H.gemm_geom(), addend=add_p, ld_add=add_ld)
+                while link is not None and link.get("gs") and len(adds) < 2:
+                    ga, _, ld_a = rows_view(link["gs"].pop())
+                    adds.append((ga, ld_a))
+                    TAP_STATS["epilogue"] += 1
+                adds += [(None, 0)] * (2 - len(adds))
+                gemm(P(gy), ldg, P(weight), Ci, 1, P(gx), Ci, Min, Ci, Co, Co, H.gemm_geom(), addend=P(adds[0][0]) if adds[0][0] is not None else None,
+                     ld_add=adds[0][1], addend2=P(adds[1][0]) if adds[1][0] is not None else None, ld_add2=adds[1][1])
             elif _patch_cc((kd, kh, kw), stride, pad, Co, Ci):      # data gradient = patch conv of dY with flipped weights
                 cc = _patch_cc((kd, kh, kw), stride, pad, Co, Ci)
                 wd = repack(weight, (Co // cc, Ci, T, cc), Co, Ci, T, 4, cc)
@@ -346,22 +356,27 @@ class ConvFn(Function):
         return gx, gw, gb, None, None, None, None, None, None, None
 
 
+TAP_STATS = {"epilogue": 0, "added": 0, "late": 0}      # grad_tap bookkeeping (tests): absorbed by a GEMM epilogue / own add pass / missed
+
+
 def _finish_link(link, gx):
     """grad_tap bookkeeping at the end of ConvFn.backward: a tapped gradient that no kernel epilogue absorbed is added here; the
     link is marked done so that a tap firing later falls back to ordinary autograd accumulation."""
     if link is not None:
-        if "g" in link and gx is not None:
-            gx = add(gx, link.pop("g").contiguous())
+        while link.get("gs") and gx is not None:
+            gx = add(gx, link["gs"].pop().contiguous())
+            TAP_STATS["added"] += 1
         link["done"] = True
     return gx
 
 
 class GradTapFn(Function):
-    """Identity on a tensor that has a second consumer whose backward can absorb this use's gradient (the Bottleneck input feeds the
-    residual add AND conv1): backward parks the gradient in `link` for conv1's data-gradient GEMM epilogue and returns nothing,
-    which removes the separate gradient-accumulation pass (read two tensors, write one) autograd would otherwise run.  The tap's node
-    is created right before the residual add, i.e. after conv1's, so the engine runs it first; if it ever ran after conv1's backward
-    (`link["done"]`) it simply returns the gradient to autograd."""
+    """Identity on a tensor that has another consumer whose backward can absorb this use's gradient (the Bottleneck input feeds the
+    residual add / the downsample convolution AND conv1; a layer output also feeds the encoder's adapt convolution): backward parks
+    the gradient in `link` for conv1's data-gradient GEMM epilogue and returns nothing, which removes the separate gradient-
+    accumulation pass (read two tensors, write one) autograd would otherwise run per extra consumer.  The tap's node is created after
+    conv1's, so the engine runs it first; if it ever ran after conv1's backward (`link["done"]`) it simply returns the gradient to
+    autograd."""
 
     @staticmethod
     def forward(ctx, x, link):
@@ -371,8 +386,9 @@ class GradTapFn(Function):
     @staticmethod
     def backward(ctx, g):
         if ctx.link.get("done"):
+            TAP_STATS["late"] += 1
             return g, None
-        ctx.link["g"] = g
+        ctx.link.setdefault("gs", []).append(g)
         return None, None
 
 
@@ -759,7 +775,58 @@ class AttentionFn(Function):
         return dqkv, None, None, None
 
 
+def flash_fwd(qkv, out, lse, mask, B, N, heads, scale, p_drop, seed, off):
+    check(lib().corrif_flash_attn_fwd(P(qkv), P(out), P(lse), P(mask), B, N, heads, scale, p_drop, seed, off, stream()), "corrif_flash_attn_fwd")
+
+
+def flash_bwd(qkv, out, lse, mask, go, dvec, dqkv, B, N, heads, scale, p_drop):
+    check(lib().corrif_flash_attn_bwd(P(qkv), P(out), P(lse), P(mask), P(go), P(dvec), P(dqkv), B, N, heads, scale, p_drop, stream()),
+          "corrif_flash_attn_bwd")
+
+
+class FlashAttentionFn(Function):
+    """The same attention core without the [B, heads, N, N] tensors (corrif_flash_attn_*): forward keeps one 64-key score tile in
+    MFMA accumulators, backward recomputes the probabilities from qkv and the saved row log-sum-exp.  Same Philox indexing as
+    AttentionFn, so both draw the identical dropout mask from one (seed, offset)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, p_drop, training):
+        qkv = qkv.contiguous()
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        scale = (C // heads) ** -0.5
+        drop = training and p_drop > 0.0
+        seed = off = 0
+        if drop:
+            seed, off = _Philox.reserve(B * heads * N * N)
+        out = torch.empty((B, N, C), dtype=torch.float32, device=qkv.device)
+        lse = torch.empty((B * heads, N), dtype=torch.float32, device=qkv.device)
+        mask = None
+        if drop:         # keep bits, 1/32 of a score tensor: drawn once by the forward, read by the backward kernels
+            mask = torch.empty(lib().corrif_flash_attn_mask_bytes(B, N, heads, p_drop) // 4, dtype=torch.int32, device=qkv.device)
+        flash_fwd(qkv, out, lse, mask, B, N, heads, scale, p_drop if drop else 0.0, seed, off)
+        ctx.save_for_backward(qkv, out, lse, mask)
+        ctx.cfg = (heads, p_drop if drop else 0.0, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        qkv, out, lse, mask = ctx.saved_tensors
+        heads, p_drop, scale = ctx.cfg
+        B, N, _ = qkv.shape
+        go = go.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dvec = torch.empty_like(lse)
+        flash_bwd(qkv, out, lse, mask, go, dvec, dqkv, B, N, heads, scale, p_drop)
+        return dqkv, None, None, None
+
+
+FLASH_ATTENTION = True      # diagnostics / A-B: False materialises the score tensor (AttentionFn)
+
+
 def attention(qkv, heads, p_drop, training):
+    if FLASH_ATTENTION and lib().corrif_flash_attn_supported(qkv.shape[1], qkv.shape[2] // (3 * heads)):
+        return FlashAttentionFn.apply(qkv, heads, p_drop, training)
     return AttentionFn.apply(qkv, heads, p_drop, training)
 
 

@@ -32,7 +32,7 @@ extern "C" {
 #define CORRIF_EUNSUPPORTED (-2)
 #define CORRIF_ELAUNCH (-3)
 
-#define CORRIF_ABI_VERSION 3   /* 2: CorrifConv3Patch.fold  3: CorrifGemm.ws / no_split (stream-K), corrif_scale, corrif_fill */
+#define CORRIF_ABI_VERSION 4   /* 2: CorrifConv3Patch.fold  3: CorrifGemm.ws / no_split (stream-K), corrif_scale, corrif_fill  4: CorrifGemm.addend2, corrif_flash_attn_* */
 int corrif_abi_version(void);
 /* name of the gfx target the library was built for ("gfx950") - host-only call */
 const char* corrif_build_arch(void);
@@ -102,6 +102,10 @@ typedef struct CorrifGemm {
      * provides `ws` with corrif_gemm_fwd_workspace(p) bytes (0 = this launch is not split; 16-byte aligned); no_split = 1 forces the
      * one-workgroup-per-tile launch (A/B measurements). */
     float* ws; int32_t no_split;
+    /* second epilogue addend (ABI 4), only with `addend`: C = act(A.B + bias + addend + addend2).  Used by the data gradient of a
+     * 1x1x1 convolution whose input has three consumers (a ResNet layer output feeds the next block's conv1, its downsample conv and
+     * the encoder's adapt conv, mmvit4.py:176-186,204-212): the other two gradients ride along instead of two accumulation passes. */
+    const float* addend2; int64_t ld_add2;
 } CorrifGemm;
 int corrif_gemm_fwd(const CorrifGemm* p, void* stream);
 size_t corrif_gemm_fwd_workspace(const CorrifGemm* p);   /* bytes of CorrifGemm.ws this launch needs; queries the device's CU count */
@@ -261,6 +265,22 @@ int corrif_softmax_rows_bwd(const float* p, float* dp_to_ds, int64_t rows, int32
 int corrif_softmax_dropout_rows(float* s, float* pd, int64_t rows, int32_t n, float scale, float p, uint64_t seed, uint64_t offset, void* stream);
 int corrif_softmax_dropout_rows_bwd(const float* pr, float* dpd_to_ds, int64_t rows, int32_t n, float scale, float p, uint64_t seed,
                                     uint64_t offset, void* stream);
+
+/* Flash-style multi-head self-attention, head dimension 64 (replaces the whole of mmvit4.py:305-312: q@k^T * scale, softmax,
+ * attn_drop, attn@v) without writing the [B, heads, N, N] score tensor.  qkv: [B][N][3*heads*64] = the qkv Linear's output, laid
+ * out as reshape(B, N, 3, heads, 64); out: [B][N][heads*64] (= the transpose(1,2).reshape of mmvit4.py:312); lse: [B*heads][N]
+ * row log-sum-exp of the scaled scores, kept for the backward.  Dropout mask = the Philox stream of corrif_dropout over the flat
+ * [B, heads, N, N] index at `offset` (p = 0: no dropout, mask may be NULL), so it equals corrif_softmax_dropout_rows on a
+ * materialised score tensor; the forward leaves it as keep bits in mask ([B*heads][N][N/32] words = corrif_flash_attn_mask_bytes,
+ * 1/32 of a score tensor) for the backward.  Backward recomputes the probabilities from qkv and lse: dvec [B*heads][N] is scratch
+ * (rowsum(dO * O)), dqkv [B][N][3*heads*64] is fully written.  Deterministic (no atomics): dq and (dk, dv) come from two kernels
+ * that own their output rows.  N must be a multiple of 128; fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout. */
+int corrif_flash_attn_supported(int32_t N, int32_t head_dim);
+size_t corrif_flash_attn_mask_bytes(int32_t B, int32_t N, int32_t heads, float p);
+int corrif_flash_attn_fwd(const float* qkv, float* out, float* lse, uint32_t* mask, int32_t B, int32_t N, int32_t heads, float scale,
+                          float p, uint64_t seed, uint64_t offset, void* stream);
+int corrif_flash_attn_bwd(const float* qkv, const float* out, const float* lse, const uint32_t* mask, const float* dout, float* dvec,
+                          float* dqkv, int32_t B, int32_t N, int32_t heads, float scale, float p, void* stream);
 
 /* Dropout with a counter-based Philox4x32-10 stream (replaces aten::bernoulli_/native_dropout at
  * mmvit4.py:302,304,336,353,355): y = x * keep/(1-p), keep = u(seed, offset + i) >= p.

@@ -355,7 +355,9 @@ def test_nearest(ops, src, dst):
 
 
 @pytest.mark.parametrize("B,N", [(2, 512), (1, 2048)])
-def test_attention(ops, B, N):
+@pytest.mark.parametrize("flash", [True, False], ids=["flash", "materialised"])
+def test_attention(ops, B, N, flash, monkeypatch):
+    monkeypatch.setattr(ops, "FLASH_ATTENTION", flash)
     heads, C = 8, 512
     qkv = rnd(B, N, 3 * C, seed=1, scale=0.5)
     qr = qkv.clone().requires_grad_()
@@ -372,8 +374,11 @@ def test_attention(ops, B, N):
     assert rel(qg.grad, qr.grad) < 1e-5
 
 
-def test_attention_dropout_fused_equals_unfused(ops):
-    """the fused softmax+dropout kernels use the same Philox stream / indexing as the element-wise dropout kernel"""
+@pytest.mark.parametrize("flash", [True, False], ids=["flash", "materialised"])
+def test_attention_dropout_fused_equals_unfused(ops, flash, monkeypatch):
+    """the flash kernels / the fused softmax+dropout kernels use the same Philox stream and indexing as the element-wise dropout
+    kernel: with one (seed, offset) all three statements of attention draw the identical mask"""
+    monkeypatch.setattr(ops, "FLASH_ATTENTION", flash)
     B, N, heads, C = 2, 512, 8, 512
     qkv = rnd(B, N, 3 * C, seed=3, scale=0.5).to(DEV)
     go = rnd(B, N, C, seed=4).to(DEV)
@@ -393,6 +398,30 @@ def test_attention_dropout_fused_equals_unfused(ops):
     assert rel(o1, o2) < 3e-6
     assert rel(q1.grad, q2.grad) < 2e-5
     assert (o1 - ops.attention(qkv, heads, 0.1, False)).abs().max().item() > 1e-3     # dropout really is active
+
+
+def test_flash_attention_matches_materialised_at_2048_tokens(ops, monkeypatch):
+    """N = 2048 (the multimodal transformer), dropout on, odd batch: the flash kernels against the materialised-score path with the
+    same Philox reservation - outputs and all three gradients - and bit-identical reruns (no atomics)."""
+    B, N, heads, C = 3, 2048, 8, 512
+    qkv = rnd(B, N, 3 * C, seed=5, scale=0.5).to(DEV)
+    go = rnd(B, N, C, seed=6).to(DEV)
+    res = {}
+    for flash in (True, False, True):
+        monkeypatch.setattr(ops, "FLASH_ATTENTION", flash)
+        ops.manual_seed(91)
+        ops.dropout(torch.ones(64, device=DEV), 0.5, True)          # a non-zero stream offset
+        q = qkv.clone().requires_grad_()
+        o = ops.attention(q, heads, 0.1, True)
+        o.backward(go)
+        res.setdefault(flash, []).append((o.detach(), q.grad))
+    torch.cuda.synchronize()
+    (o1, g1), (o3, g3) = res[True]
+    (o2, g2), = res[False]
+    assert torch.equal(o1, o3) and torch.equal(g1, g3)
+    assert rel(o1, o2) < 3e-6
+    for sl in (slice(0, C), slice(C, 2 * C), slice(2 * C, 3 * C)):      # dq, dk, dv
+        assert rel(g1[..., sl], g2[..., sl]) < 2e-5
 
 
 @pytest.mark.parametrize("B", [1, 2, 3, 4])

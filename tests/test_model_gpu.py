@@ -396,6 +396,29 @@ def test_module_surface():
     torch.cuda.empty_cache()                                                # F2_MAIN.py:307-308
 
 
+def test_multi_consumer_gradients_ride_in_gemm_epilogues():
+    """Every Bottleneck input (residual add or downsample conv next to conv1) and every layer input (adapt conv as a third consumer)
+    hands its extra gradients to conv1's data-gradient GEMM epilogue (ops.grad_tap): 3 encoders x (16 blocks + 4 adapt taps) = 60
+    tapped gradients per step, none of them late (fallen back to autograd's accumulation) and none needing an add pass of its own;
+    switching the mechanism off gives the same gradients up to the association of the sums."""
+    import mmvit4
+    import ops
+    case = dict(B=2, D=3, H=64, W=64, mode="train_nodrop", conv_gain=1.0, wseed=3)
+    for k in ops.TAP_STATS:
+        ops.TAP_STATS[k] = 0
+    m1, _, _, _, _ = run_hip(case)
+    assert ops.TAP_STATS == {"epilogue": 60, "added": 0, "late": 0}, ops.TAP_STATS
+    mmvit4.GRAD_TAP = False
+    try:
+        m2, _, _, _, _ = run_hip(case)
+    finally:
+        mmvit4.GRAD_TAP = True
+    g2 = dict(m2.named_parameters())
+    for k, p in m1.named_parameters():
+        if p.grad is not None:
+            assert ((p.grad - g2[k].grad).norm() / g2[k].grad.norm().clamp_min(1e-30)).item() < 2e-2, k      # a lost gradient would be O(1)
+
+
 def test_determinism():
     case = dict(B=2, D=3, H=32, W=32, mode="train_nodrop", conv_gain=1.0, wseed=3)
     m1, p1, _, l1, _ = run_hip(case)
