@@ -213,6 +213,10 @@ def main():
         model.decoder_split = int(os.environ["CORRIF_DECODER_SPLIT"])
     if os.environ.get("CORRIF_STREAM_K") is not None:        # A/B switch: 0 = every GEMM as one workgroup per tile
         ops.STREAM_K = os.environ["CORRIF_STREAM_K"] == "1"
+    if os.environ.get("CORRIF_AUTO_STREAMS") is not None:    # A/B switch: 0 = keep the multi-stream schedule whatever the memory estimate says
+        model.auto_streams = os.environ["CORRIF_AUTO_STREAMS"] == "1"
+    if os.environ.get("CORRIF_FLASH") is not None:           # A/B switch: 0 = materialised attention scores
+        ops.FLASH_ATTENTION = os.environ["CORRIF_FLASH"] == "1"
     if os.environ.get("CORRIF_SERIAL") == "1":          # profiling aid: one stream, clean per-kernel attribution
         model.concurrent_branches = False
         model.decoder_fuse.concurrent_skips = False

@@ -101,6 +101,8 @@ _SIGS = {
     "corrif_flash_attn_fwd": (i32, [ptr, ptr, ptr, ptr, i32, i32, i32, f32, f32, u64, u64, ptr]),
     "corrif_flash_attn_bwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, f32, f32, ptr]),
     "corrif_dropout": (i32, [ptr, ptr, i64, f32, u64, u64, ptr]),
+    "corrif_depth_bcast_add": (i32, [ptr, i64, ptr, i64, i32, i32, i32, i32, i32, ptr]),
+    "corrif_depth_class_reduce": (i32, [ptr, i64, ptr, i64, i32, i32, i32, i32, i32, ptr]),
     "corrif_add": (i32, [ptr, ptr, ptr, i64, ptr]),
     "corrif_add_bcast_rows": (i32, [ptr, ptr, i64, ptr, i64, ptr]),
     "corrif_gelu_fwd": (i32, [ptr, ptr, i64, ptr]),

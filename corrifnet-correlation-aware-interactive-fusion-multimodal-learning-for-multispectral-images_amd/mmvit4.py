@@ -323,6 +323,7 @@ class Decoder_fuse(nn.Module):
         self.RFM1 = fusion_prenorm(b * 3)
         self.final_conv = Conv3dP(8, 3, 1)
         self.concurrent_skips = True
+        self.compact_skips = True       # diagnostics / A-B: False materialises the up-sampled skip tensors and the concat buffers
         self._side = None
         self._edges = {}
 
@@ -332,10 +333,32 @@ class Decoder_fuse(nn.Module):
                   (self.RFM3, x3, 32, self.d3_c1, self.d3_c2, self.d3_out),
                   (self.RFM2, x2, 64, self.d2_c1, self.d2_c2, self.d2_out),
                   (self.RFM1, x1, 128, self.d1_c1, self.d1_c2, self.d1_out))
-        cats = [torch.empty((B, n, n, n, skip.shape[-1] + c1.conv.weight.shape[0]), dtype=torch.float32, device=dev)
-                for _, skip, n, c1, _, _ in stages]
-        # skip branches (RFM -> nearest upsample into the concat slice) only depend on the early-fusion outputs: run them on a
-        # side stream next to the main chain (RFM5 -> up2 -> d*_c1 ...), which needs each of them only at its concat
+        # Compact skip branch.  F.interpolate(nearest) of the RFM output from Ds to n = f * Ds depth slices (mmvit4.py:271-286) is
+        # constant along depth inside each block of f slices, so its share of the replicate-padded 3x3x3 convolution d*_c2 takes three
+        # distinct values per block (first slice / interior / last slice).  For f >= 8 that share is evaluated on a grid of 3 * Ds slices
+        # - nearest-up-sampling to (3 Ds, n, n), the same convolution with the weight's skip channels, no bias - and broadcast into the
+        # convolution of the other (d*_c1) channels: d1_c2 at 4 bands runs 8 + 24 * 12/128 instead of 32 input channels' worth of
+        # forward, data-gradient and weight-gradient work, the 128^3 x 24-channel up-sampled tensor and the concat buffer disappear.
+        # Same arithmetic, summed in a different order (the sum over input channels is split in two).
+        fs = []
+        for _, skip, n, _, _, _ in stages:
+            Ds = skip.shape[1]
+            fs.append(n // Ds if (self.compact_skips and n % Ds == 0 and n // Ds >= 8) else 0)
+        cats = [None if fs[l] else torch.empty((B, n, n, n, skip.shape[-1] + c1.conv.weight.shape[0]), dtype=torch.float32, device=dev)
+                for l, (_, skip, n, c1, _, _) in enumerate(stages)]
+
+        def skip_branch(l):
+            rfm, skip, n, _, c2, _ = stages[l]
+            cs = skip.shape[-1]
+            s = rfm(skip)
+            if not fs[l]:
+                return ops.nearest(s, (n, n, n), out=cats[l][..., :cs])         # F.interpolate nearest (mmvit4.py:271-286)
+            w_s, w_y = ops.split_weight(c2.conv.weight, cs)
+            sc = ops.nearest(s, (3 * skip.shape[1], n, n))                       # the three depth classes of every block
+            return ops.conv3d(sc, w_s, None, c2.conv.stride, c2.conv.pad, c2.conv.replicate), w_y
+
+        # skip branches (RFM -> nearest upsample -> their share of d*_c2 / the concat slice) only depend on the early-fusion outputs:
+        # run them on a side stream next to the main chain (RFM5 -> up2 -> d*_c1 ...), which needs each of them only at d*_c2
         parts_s = [None] * 4
         if self._side is None:
             self._side = {}
@@ -348,13 +371,12 @@ class Decoder_fuse(nn.Module):
             edges = self._edges.setdefault(lane, _Edges())
             edges.reset()
             edges.edge(cur, side)
-            for t in (x1, x2, x3, x4) + tuple(cats):      # allocated on the caller's stream, used (and saved) on the side stream
+            for t in (x1, x2, x3, x4) + tuple(c for c in cats if c is not None):      # allocated on the caller's stream, used (and saved) on the side stream
                 _rs(t, side)
             events = []
             with torch.cuda.stream(side):
-                for l, (rfm, skip, n, _, _, _) in enumerate(stages):
-                    cs = skip.shape[-1]
-                    parts_s[l] = ops.nearest(rfm(skip), (n, n, n), out=cats[l][..., :cs])     # F.interpolate nearest (mmvit4.py:271-286)
+                for l in range(4):
+                    parts_s[l] = skip_branch(l)
                     events.append(edges.mark(side))
         y = self.RFM5(x5)
         if self.RFM5_reduce is not None:
@@ -363,13 +385,19 @@ class Decoder_fuse(nn.Module):
             cs = skip.shape[-1]
             cat = cats[l]
             up = ops.trilinear(y, (n, n, n))                                   # self.up2, align_corners (mmvit4.py:243)
-            part_y = c1(up, out=cat[..., cs:])                                 # d*_c1: 3x3x3 replicate -> ReLU -> IN
+            part_y = c1(up) if fs[l] else c1(up, out=cat[..., cs:])            # d*_c1: 3x3x3 replicate -> ReLU -> IN
             if use_side:
                 torch.cuda.current_stream().wait_event(events[l])
-                _rs(parts_s[l], torch.cuda.current_stream())
+                for t in (parts_s[l] if fs[l] else (parts_s[l],)):
+                    _rs(t, torch.cuda.current_stream())
             else:
-                parts_s[l] = ops.nearest(rfm(skip), (n, n, n), out=cat[..., :cs])
-            y = cout(c2(ops.cat_channels(cat, parts_s[l], part_y)))
+                parts_s[l] = skip_branch(l)
+            if fs[l]:
+                ys, w_y = parts_s[l]
+                yc = ops.conv3d(part_y, w_y, c2.conv.bias, c2.conv.stride, c2.conv.pad, c2.conv.replicate)
+                y = cout(c2.norm(ops.depth_bcast_add(yc, ys, fs[l])))
+            else:
+                y = cout(c2(ops.cat_channels(cat, parts_s[l], part_y)))
         up = ops.trilinear(y, (1, 224, 224))                                   # up_to_224 (mmvit4.py:263): depth slice 0 only
         return ops.head(up, self.final_conv.weight, self.final_conv.bias)      # final_conv + sigmoid (mmvit4.py:290-291)
 

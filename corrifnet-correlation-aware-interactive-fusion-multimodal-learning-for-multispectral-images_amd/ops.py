@@ -402,6 +402,70 @@ def conv3d(x, weight, bias=None, stride=(1, 1, 1), pad=(0, 0, 0), replicate=Fals
     return ConvFn.apply(x, weight, bias, tuple(stride), tuple(pad), bool(replicate), out, act, stats, grad_link)
 
 
+class SplitWeightFn(Function):
+    """(w[:, :cs], w[:, cs:]) of a convolution weight [Co, C, kd, kh, kw] as two contiguous tensors (strided copy kernel); backward
+    reassembles the two gradients into one tensor of the parameter's shape."""
+
+    @staticmethod
+    def forward(ctx, w, cs):
+        Co, C = w.shape[:2]
+        T = w.shape[2] * w.shape[3] * w.shape[4]
+        w = w.contiguous()
+        a = torch.empty((Co, cs) + tuple(w.shape[2:]), dtype=torch.float32, device=w.device)
+        b = torch.empty((Co, C - cs) + tuple(w.shape[2:]), dtype=torch.float32, device=w.device)
+        check(lib().corrif_copy2d(w.data_ptr(), C * T, P(a), cs * T, Co, cs * T, 0, stream()), "corrif_copy2d")
+        check(lib().corrif_copy2d(w.data_ptr() + 4 * cs * T, C * T, P(b), (C - cs) * T, Co, (C - cs) * T, 0, stream()), "corrif_copy2d")
+        ctx.cfg = (tuple(w.shape), cs, T)
+        return a, b
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        shape, cs, T = ctx.cfg
+        Co, C = shape[:2]
+        gw = torch.empty(shape, dtype=torch.float32, device=(ga if ga is not None else gb).device)
+        if ga is None or gb is None:
+            check(lib().corrif_fill(gw.data_ptr(), gw.numel(), 0.0, stream()), "corrif_fill")
+        for g, off, n in ((ga, 0, cs), (gb, cs, C - cs)):
+            if g is None:
+                continue
+            g = g.contiguous()
+            check(lib().corrif_copy2d(P(g), n * T, gw.data_ptr() + 4 * off * T, C * T, Co, n * T, 0, stream()), "corrif_copy2d")
+        return gw, None
+
+
+def split_weight(w, cs):
+    return SplitWeightFn.apply(w, cs)
+
+
+class DepthBcastAddFn(Function):
+    """y[b, d] += ys[b, cls(d)] in place (corrif_depth_bcast_add): `ys` lives on the compact depth grid of 3 * (D / f) slices, see
+    Decoder_fuse.forward.  Backward: the gradient passes through to y and is class-reduced for ys."""
+
+    @staticmethod
+    def forward(ctx, y, ys, f):
+        B, D, Hh, W, C = y.shape
+        yv, _, ldy = rows_view(y)
+        sv, _, lds = rows_view(ys)
+        assert yv is y and tuple(ys.shape) == (B, 3 * (D // f), Hh, W, C) and D % f == 0
+        check(lib().corrif_depth_bcast_add(P(y), ldy, P(sv), lds, B, D, Hh * W, C, f, stream()), "corrif_depth_bcast_add")
+        ctx.mark_dirty(y)
+        ctx.cfg = (f, tuple(ys.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        f, sshape = ctx.cfg
+        B, D, Hh, W, C = g.shape
+        gv, _, ldg = rows_view(g)
+        gs = torch.empty(sshape, dtype=torch.float32, device=g.device)
+        check(lib().corrif_depth_class_reduce(P(gv), ldg, P(gs), C, B, D, Hh * W, C, f, stream()), "corrif_depth_class_reduce")
+        return g, gs, None
+
+
+def depth_bcast_add(y, ys, f):
+    return DepthBcastAddFn.apply(y, ys, f)
+
+
 # --------------------------------------------------------------------------------------- linear
 class LinearFn(Function):
     @staticmethod

@@ -354,6 +354,34 @@ def test_nearest(ops, src, dst):
     assert rel(ncdhw(xg.grad), xr.grad) < 2e-6
 
 
+@pytest.mark.parametrize("f", [8, 32])
+def test_depth_class_broadcast_and_reduce(ops, f):
+    """y[b,d] += ys[b, cls(d)] and its adjoint (class 3k + {0 first, 1 interior, 2 last} of up-sampling block k); and the identity the
+    decoder relies on: a replicate-padded 3x3x3 conv of a depth-nearest-up-sampled tensor equals the broadcast of the same conv on the
+    compact 3-slices-per-block grid."""
+    B, Ds, Hh, W, C = 2, 3, 5, 8, 8
+    D = f * Ds
+    cls = torch.tensor([3 * (d // f) + (0 if d % f == 0 else 2 if d % f == f - 1 else 1) for d in range(D)])
+    y = rnd(B, D, Hh, W, C, seed=1)
+    ys = rnd(B, 3 * Ds, Hh, W, C, seed=2)
+    yg = y.clone().to(DEV).requires_grad_()
+    sg = ys.clone().to(DEV).requires_grad_()
+    out = ops.depth_bcast_add(yg * 1.0, sg, f)
+    go = rnd(B, D, Hh, W, C, seed=3)
+    out.backward(go.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(out.detach().cpu(), y + ys[:, cls])
+    gs_ref = torch.zeros_like(ys).index_add_(1, cls, go)
+    assert torch.equal(yg.grad.cpu(), go) and rel(sg.grad, gs_ref) < 1e-6
+    # the convolution identity, on the CPU with stock ops
+    x = rnd(1, 4, Ds, 6, 6, seed=4)
+    w = rnd(5, 4, 3, 3, 3, seed=5)
+    conv = lambda t: F.conv3d(F.pad(t, (1, 1, 1, 1, 1, 1), mode="replicate"), w)
+    full = conv(x.repeat_interleave(f, dim=2))
+    compact = conv(x.repeat_interleave(3, dim=2))
+    assert (full - compact[:, :, cls]).abs().max().item() < 1e-5
+
+
 @pytest.mark.parametrize("B,N", [(2, 512), (1, 2048)])
 @pytest.mark.parametrize("flash", [True, False], ids=["flash", "materialised"])
 def test_attention(ops, B, N, flash, monkeypatch):

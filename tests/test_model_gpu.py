@@ -419,6 +419,29 @@ def test_multi_consumer_gradients_ride_in_gemm_epilogues():
             assert ((p.grad - g2[k].grad).norm() / g2[k].grad.norm().clamp_min(1e-30)).item() < 2e-2, k      # a lost gradient would be O(1)
 
 
+def test_compact_skip_branch_equals_materialised():
+    """Decoder_fuse evaluates the nearest-up-sampled skip channels' share of d*_c2 on a compact depth grid (three depth classes per
+    up-sampling block) and broadcasts it; with the switch off it materialises the up-sampled tensor and the concat buffer as the
+    reference does (mmvit4.py:271-287).  Same arithmetic up to the order of the channel sum: prediction and every gradient agree to
+    fp32 rounding amplified by the InstanceNorm chain.  4 bands: levels 1-3 (f = 32, 16, 8) take the compact path."""
+    case = dict(B=2, D=4, H=64, W=64, mode="train_nodrop", conv_gain=1.0, wseed=9)
+    import ops
+    res = []
+    for compact in (True, False):
+        model, _ = build_hip(case)
+        model.decoder_fuse.compact_skips = compact
+        x, mask = helpers.make_inputs(case["B"], case["D"], case["H"], case["W"])
+        pred = model(x.to(DEV))
+        ops.bce_with_logits_mean(pred, mask.to(DEV)).backward()
+        torch.cuda.synchronize()
+        res.append((pred.detach(), {k: p.grad for k, p in model.named_parameters() if p.grad is not None}))
+    (p1, g1), (p2, g2) = res
+    assert (p1 - p2).abs().max().item() < 2e-5
+    assert g1.keys() == g2.keys()
+    worst = max(((g1[k] - g2[k]).norm() / g2[k].norm().clamp_min(1e-30)).item() for k in g1)
+    assert worst < 2e-3, worst
+
+
 def test_determinism():
     case = dict(B=2, D=3, H=32, W=32, mode="train_nodrop", conv_gain=1.0, wseed=3)
     m1, p1, _, l1, _ = run_hip(case)

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 PKG=$(ls -d corrifnet*_amd)
 mkdir -p variants/obj_$1
 for f in $PKG/csrc/*.hip; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -c $f -o variants/obj_$1/$(basename $f .hip).o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $EXTRA -c $f -o variants/obj_$1/$(basename $f .hip).o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libcorrif_$1.so variants/obj_$1/*.o
