@@ -367,16 +367,19 @@ __device__ __forceinline__ void wg_half(f32x4 (&a)[NG], const float (&areg)[NG],
         for (int g = 0; g < NG; ++g) a[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(areg[g], x[Vs], a[g], 4, HB * 8 + Vs, 0);
     }(), ...);
 }
-// 8 voxels of one w-row for this lane's column: xaddr includes the column offset, the w-row base and the half; voxel v sits 16 floats on
+// 8 voxels of one w-row for this lane's column: xaddr includes the column offset, the w-row base and the half; voxel v sits CP floats on
+template <int CP>
 __device__ __forceinline__ void wg_load8(float (&x)[8], const float* __restrict__ xaddr) {
 #pragma unroll
-    for (int v = 0; v < 8; ++v) x[v] = xaddr[v * 16];
+    for (int v = 0; v < 8; ++v) x[v] = xaddr[v * CP];
 }
 
-template <int NG, int NCH, int NPF>
+// CC = channels per chunk: 16 (7 column groups of 64 lanes for the 432 (tap, ci) columns) or 8 (4 groups for 216 columns: layers whose
+// input channel count is not a multiple of 16 - the 8-channel d1_c1 share of d1_c2, the 24 skip channels on the compact grid).
+template <int NG, int NCH, int NPF, int CC>
 __global__ __launch_bounds__(256, 2) void conv3_patch_wgrad_kernel(PatchWgArgs p) {
-    constexpr int CC = 16, CP = 16, TW = 16, PW = TW + 2, DP = 4 * NG + 4, KC = 27 * CC;   // CP = 16: taps 1 apart in w sit 16 banks apart
-    constexpr int C4 = CC / 4;
+    constexpr int CP = CC, TW = 16, PW = TW + 2, DP = 4 * NG + 4, KC = 27 * CC;   // CP = CC: taps 1 apart in w sit CC banks apart
+    constexpr int C4 = CC / 4, NCG = (KC + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TD = 1 << p.ltd, TH = 1 << p.lth, PH = TH + 2;
     const int NPV = (TD + 2) * PH * PW;
@@ -386,21 +389,21 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_wgrad_kernel(PatchWgArgs p
     const int c_lo = blockIdx.z * (CC * NCH);
 
     // lane -> column (tap, ci) of column group cg: patch offset of the tap + channel
-    int colbase[7];
-    bool colok[7];
+    int colbase[NCG];
+    bool colok[NCG];
 #pragma unroll
-    for (int cg = 0; cg < 7; ++cg) {
+    for (int cg = 0; cg < NCG; ++cg) {
         const int col = cg * 64 + lane;
         colok[cg] = col < KC;
         const int tap = colok[cg] ? col / CC : 0, ci = colok[cg] ? col % CC : 0;
         const int td = tap / 9, th = (tap / 3) % 3, tw = tap % 3;
         colbase[cg] = ((td * PH + th) * PW + tw) * CP + ci;
     }
-    f32x4 acc[NCH][7][NG];
+    f32x4 acc[NCH][NCG][NG];
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int cg = 0; cg < 7; ++cg)
+        for (int cg = 0; cg < NCG; ++cg)
 #pragma unroll
             for (int g = 0; g < NG; ++g) acc[c][cg][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_wgrad_kernel(PatchWgArgs p
 #pragma unroll
         for (int u = 0; u < NPF; ++u) {
             const int ic = min(tid + u * 256, total - 1);
-            const int pv = ic >> 2, c4 = ic & 3;
+            const int pv = ic / C4, c4 = ic - pv * C4;
             const uint32_t pd = fdiv((uint32_t)pv, p.dHW);
             const uint32_t rem = pv - pd * p.dHW.d;
             const uint32_t ph = fdiv(rem, p.dW);
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_wgrad_kernel(PatchWgArgs p
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int ic = min(i0 + u * 256, total - 1);
-                const int pv = ic >> 2, c4 = ic & 3;
+                const int pv = ic / C4, c4 = ic - pv * C4;
                 const uint32_t pd = fdiv((uint32_t)pv, p.dHW);
                 const uint32_t rem = pv - pd * p.dHW.d;
                 const uint32_t ph = fdiv(rem, p.dW);
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_wgrad_kernel(PatchWgArgs p
             auto rowoff_of = [&](int r) { return (((r >> p.lth) * PH + (r & (TH - 1))) * PW) * CP; };
             float xb[2][8];
             float areg[2][NG];
-            wg_load8(xb[0], patch + rowoff_of(wave * 4) + colbase[0]);
+            wg_load8<CP>(xb[0], patch + rowoff_of(wave * 4) + colbase[0]);
 #pragma unroll
             for (int g = 0; g < NG; ++g) areg[0][g] = dys[(wave * 4 * 16 + (lane >> 2)) * DP + g * 4 + (lane & 3)];
 #pragma unroll
@@ -540,13 +543,13 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_wgrad_kernel(PatchWgArgs p
                     for (int g = 0; g < NG; ++g) areg[(vq + 1) & 1][g] = dys[((r + 1) * 16 + (lane >> 2)) * DP + g * 4 + (lane & 3)];
                 }
 #pragma unroll
-                for (int cg = 0; cg < 7; ++cg) {
+                for (int cg = 0; cg < NCG; ++cg) {
                     // first half: voxels 0..7 are in xb[0]; request voxels 8..15, then the next group's (or next row's) first half
-                    wg_load8(xb[1], patch + ro + colbase[cg] + 8 * 16);
+                    wg_load8<CP>(xb[1], patch + ro + colbase[cg] + 8 * CP);
                     __builtin_amdgcn_sched_barrier(0);
                     wg_half<NG, 0>(acc[ch][cg], areg[vq & 1], xb[0], std::make_integer_sequence<int, 8>{});
-                    if (cg + 1 < 7) wg_load8(xb[0], patch + ro + colbase[cg + 1]);
-                    else if (vq + 1 < 4) wg_load8(xb[0], patch + ro_next + colbase[0]);
+                    if (cg + 1 < NCG) wg_load8<CP>(xb[0], patch + ro + colbase[cg + 1]);
+                    else if (vq + 1 < 4) wg_load8<CP>(xb[0], patch + ro_next + colbase[0]);
                     __builtin_amdgcn_sched_barrier(0);
                     wg_half<NG, 1>(acc[ch][cg], areg[vq & 1], xb[1], std::make_integer_sequence<int, 8>{});
                 }
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_wgrad_kernel(PatchWgArgs p
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-        for (int cg = 0; cg < 7; ++cg) {
+        for (int cg = 0; cg < NCG; ++cg) {
             if (!colok[cg]) continue;
             const int col = cg * 64 + lane;
             const int tap = col / CC, ci = c_lo + ch * CC + col % CC;
@@ -572,15 +575,16 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_wgrad_kernel(PatchWgArgs p
         }
 }
 
+static int wg_cc(int Ci) { return (Ci & 15) ? 8 : 16; }
 static void wg_cfg(int Ci, int Co, int& NG, int& NCH, int& nz, int& wgs) {
     NG = (Co + 3) / 4;
-    NCH = 1;        // one 16-channel chunk per workgroup: with the next item prefetched in registers there is no room for more accumulators
-    nz = Ci / (16 * NCH);
+    NCH = 1;        // one channel chunk per workgroup: with the next item prefetched in registers there is no room for more accumulators
+    nz = Ci / (wg_cc(Ci) * NCH);
     wgs = 512 / nz;
     if (wgs < 1) wgs = 1;
 }
 extern "C" int corrif_conv3_patch_wgrad_slots(int32_t Ci, int32_t Co) {
-    if (Co <= 0 || Co > 16 || (Co & 3) || Ci <= 0 || (Ci & 15)) return 0;
+    if (Co <= 0 || Co > 16 || (Co & 3) || Ci <= 0 || (Ci & 7)) return 0;
     int NG, NCH, nz, wgs;
     wg_cfg(Ci, Co, NG, NCH, nz, wgs);
     return wgs * 4;
@@ -589,26 +593,26 @@ extern "C" size_t corrif_conv3_patch_wgrad_workspace(int32_t Ci, int32_t Co) {
     return (size_t)corrif_conv3_patch_wgrad_slots(Ci, Co) * Co * 27 * Ci * sizeof(float);
 }
 
-template <int NG, int NCH, int NPF>
+template <int NG, int NCH, int NPF, int CC>
 static int launch_wg_npf(const PatchWgArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     static bool done = false;
     if (!done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_patch_wgrad_kernel<NG, NCH, NPF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_patch_wgrad_kernel<NG, NCH, NPF, CC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess) {
             (void)hipGetLastError();
             return CORRIF_ELAUNCH;
         }
         done = true;
     }
-    hipLaunchKernelGGL((conv3_patch_wgrad_kernel<NG, NCH, NPF>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv3_patch_wgrad_kernel<NG, NCH, NPF, CC>), grid, dim3(256), lds, s, a);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
-template <int NG, int NCH>
+template <int NG, int NCH, int CC>
 static int launch_wg(const PatchWgArgs& a, dim3 grid, size_t lds, int npv, hipStream_t s) {
-    constexpr int NPF_STD = (648 * 4 + 255) / 256, NPF_MAX = (972 * 4 + 255) / 256;     // halo float4 per thread (16-channel chunks)
-    if (npv * 4 <= NPF_STD * 256) return launch_wg_npf<NG, NCH, NPF_STD>(a, grid, lds, s);
-    if (npv * 4 <= NPF_MAX * 256) return launch_wg_npf<NG, NCH, NPF_MAX>(a, grid, lds, s);
+    constexpr int C4 = CC / 4, NPF_STD = (648 * C4 + 255) / 256, NPF_MAX = (972 * C4 + 255) / 256;     // halo float4 per thread
+    if (npv * C4 <= NPF_STD * 256) return launch_wg_npf<NG, NCH, NPF_STD, CC>(a, grid, lds, s);
+    if (npv * C4 <= NPF_MAX * 256) return launch_wg_npf<NG, NCH, NPF_MAX, CC>(a, grid, lds, s);
     return CORRIF_EUNSUPPORTED;
 }
 
@@ -636,16 +640,24 @@ extern "C" int corrif_conv3_patch_wgrad(const CorrifConv3PatchWgrad* q, void* st
     a.dT0 = make_fastdiv((uint32_t)(a.ntd * a.nth * a.ntw));
     a.dT1 = make_fastdiv((uint32_t)(a.nth * a.ntw));
     a.dT2 = make_fastdiv((uint32_t)a.ntw);
-    const size_t lds = (size_t)(256 * (4 * NG + 4) + (TD + 2) * PH * 18 * 16) * sizeof(float);
+    const int CC = wg_cc(q->Ci);
+    const size_t lds = (size_t)(256 * (4 * NG + 4) + (TD + 2) * PH * 18 * CC) * sizeof(float);
     if (lds > 160 * 1024) return CORRIF_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(wgs, 1, nz);          // slabs of workgroups that own no tile stay zero: the kernel still writes them
     int rc = CORRIF_EUNSUPPORTED;
     const int npv = (TD + 2) * PH * 18;
-    if (NG == 1 && NCH == 1) rc = launch_wg<1, 1>(a, grid, lds, npv, s);
-    else if (NG == 2 && NCH == 1) rc = launch_wg<2, 1>(a, grid, lds, npv, s);
-    else if (NG == 3) rc = launch_wg<3, 1>(a, grid, lds, npv, s);
-    else if (NG == 4) rc = launch_wg<4, 1>(a, grid, lds, npv, s);
+    if (CC == 16) {
+        if (NG == 1 && NCH == 1) rc = launch_wg<1, 1, 16>(a, grid, lds, npv, s);
+        else if (NG == 2 && NCH == 1) rc = launch_wg<2, 1, 16>(a, grid, lds, npv, s);
+        else if (NG == 3) rc = launch_wg<3, 1, 16>(a, grid, lds, npv, s);
+        else if (NG == 4) rc = launch_wg<4, 1, 16>(a, grid, lds, npv, s);
+    } else {
+        if (NG == 1 && NCH == 1) rc = launch_wg<1, 1, 8>(a, grid, lds, npv, s);
+        else if (NG == 2 && NCH == 1) rc = launch_wg<2, 1, 8>(a, grid, lds, npv, s);
+        else if (NG == 3) rc = launch_wg<3, 1, 8>(a, grid, lds, npv, s);
+        else if (NG == 4) rc = launch_wg<4, 1, 8>(a, grid, lds, npv, s);
+    }
     if (rc != CORRIF_OK) return rc;
     return corrif_slab_reduce(q->ws, q->dW, (int64_t)q->Co * 27 * q->Ci, wgs * 4, stream);
 }

@@ -64,6 +64,11 @@ CONVS = [
     # replicate padding with n % (4, 4, 16) == 0: the data gradient folds the padding adjoint in its epilogue (every tile touches a border)
     ("3x3x3_rep_16_8_fold", 16, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (2, 4, 8, 16), True),
     ("3x3x3_rep_8_24_fold", 8, 24, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (1, 8, 4, 32), False),
+    # input channel counts that are multiples of 8 but not of 16 (the two halves of d1_c2 on the compact skip path): 8-channel chunks
+    # in the patch weight-gradient kernel (4 column groups), also on a shallow grid and over many tiles
+    ("3x3x3_rep_8_8", 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (2, 8, 8, 32), True),
+    ("3x3x3_rep_24_8_many_tiles", 24, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (2, 12, 64, 64), False),
+    ("3x3x3_rep_24_16_shallow", 24, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), True, (1, 2, 20, 24), True),
     ("1x1_12_to_4", 12, 4, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 5, 6, 7), True),
     ("1x1_16_16", 16, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 7, 9, 11), True),
     ("1x1_n8", 8, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, (2, 6, 6, 6), True),
