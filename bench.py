@@ -292,11 +292,24 @@ def main():
                                       "(BASELINE configs[1])" % (args.bands, args.size, args.size, B),
                           "global_batch": world * B, "parallelism": "dp%d" % world, "loss": float(loss.item()),
                           "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2)}}
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_mfma_traffic.json")
-        if os.path.exists(tpath) and B == 32 and args.bands == 4 and args.size == 224:
-            try:      # HBM bytes of the MFMA kernel family for ONE step of this workload, from committed rocprofv3 PMC passes
-                traffic = float(json.load(open(tpath))["mfma_family_hbm_bytes_per_step"])
+        # HBM bytes of the MFMA kernel family for ONE step of this workload, from the newest committed rocprofv3 PMC passes
+        # (profiles/r??_mfma_traffic.json).  Quoted only while the kernel sources still are the ones the counters were taken with
+        # (sha1 of csrc/ stored by tools/reduce_traffic.py); otherwise null - a stale number is worse than none.
+        traffic, traffic_src = None, None
+        import glob
+        import hashlib
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_mfma_traffic.json")))
+        if cands and B == 32 and args.bands == 4 and args.size == 224:
+            try:
+                tj = json.load(open(cands[-1]))
+                h = hashlib.sha1()
+                for f in sorted(glob.glob(os.path.join(PKG, "csrc", "*"))):
+                    h.update(open(f, "rb").read())
+                traffic_src = os.path.basename(cands[-1])
+                if tj.get("csrc_sha1") == h.hexdigest():
+                    traffic = float(tj["mfma_family_hbm_bytes_per_step"])
+                else:
+                    traffic_src += " (stale: csrc/ changed since the counters were collected - not quoted)"
             except Exception:
                 traffic = None
         if timer:
@@ -306,7 +319,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                                "traffic_note": "HBM bytes per step of the same launches (sum over the MFMA family), rocprofv3 FETCH_SIZE x2 + "
-                                               "WRITE_SIZE from separate --pmc passes (profiles/r01_mfma_traffic.json); algorithmic = 243 GB",
+                                               "WRITE_SIZE from separate --pmc passes (profiles/%s); algorithmic = 243 GB" % traffic_src,
                                "kernel": "gemm_fwd_kernel+wgrad_kernel+conv3_patch_kernel+flash_* (fp32 MFMA implicit GEMM / patch conv / attention)",
                                "launches_per_step": n // max(kt_steps, 1), "mfma_ms_per_step": round(ms / max(kt_steps, 1), 3),
                                "algorithmic_gflop_per_step": round(fl / max(kt_steps, 1) / 1e9, 1),

@@ -778,14 +778,26 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
 }
 
+// Row splits of a weight gradient: tiles * splits workgroups should fill the resident workgroup slots of the chip evenly (the kernels
+// run 5 workgroups per CU: 96-102 VGPRs, 26 KB of LDS).  The smallest split count whose last wave of workgroups is >= 93 % full wins
+// (fewer splits = fewer slabs to write and reduce, longer K loops); it used to be ceil(2048 / tiles), which left e.g. the e4 3x3
+// gradients (72 tiles) at 2088 workgroups = 1.63 waves of 1280 slots.
 static int pick_splits(int R, int M, int N, int BM, int BN) {
-    int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    int64_t want = (2048 + tiles - 1) / tiles;
+    const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int64_t maxs = R / 256;                 // at least 8 K-tiles of work per split
-    if (want > maxs) want = maxs;
-    if (want < 1) want = 1;
-    if (want > 4096) want = 4096;
-    return (int)want;
+    if (maxs < 1) maxs = 1;
+    if (maxs > 4096) maxs = 4096;
+    const int64_t slots = 5 * 256;
+    if (tiles * maxs <= slots) return (int)maxs;          // cannot even fill one wave: take all the parallelism there is
+    int64_t best = 1;
+    double best_eff = 0.0;
+    for (int64_t sp = (slots + tiles - 1) / tiles; sp <= maxs && sp * tiles <= 4 * slots; ++sp) {
+        const int64_t wgs = sp * tiles, waves = (wgs + slots - 1) / slots;
+        const double eff = (double)wgs / (double)(waves * slots);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = sp; }
+        if (eff >= 0.93) return (int)sp;
+    }
+    return (int)best;
 }
 static void wgrad_tile(int M, int N, int& BM, int& BN) {
     BM = (M <= 32) ? 32 : 64;
