@@ -779,23 +779,23 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 }
 
 // Row splits of a weight gradient: tiles * splits workgroups should fill the resident workgroup slots of the chip evenly (the kernels
-// run 5 workgroups per CU: 96-102 VGPRs, 26 KB of LDS).  The smallest split count whose last wave of workgroups is >= 93 % full wins
-// (fewer splits = fewer slabs to write and reduce, longer K loops); it used to be ceil(2048 / tiles), which left e.g. the e4 3x3
-// gradients (72 tiles) at 2088 workgroups = 1.63 waves of 1280 slots.
+// run 5 workgroups per CU: 96-102 VGPRs, 26 KB of LDS), but every split also costs a slab of M x N floats written and read back by the
+// reduction.  Cost model: time ~ flops / (fill x 85 TFLOP/s) + 2 x splits x M x N x 4 B / 3 TB/s; the split count with the smallest
+// estimate wins (it used to be ceil(2048 / tiles): 1.6 waves of workgroups for most encoder shapes, e.g. 2088 workgroups on 1280 slots
+// for the e4 3x3 gradients; measured 60 -> 73 TF/s on the e2 1x1 gradient, 82 -> 87 on e4's, whole step -0.5 %).
 static int pick_splits(int R, int M, int N, int BM, int BN) {
     const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int64_t maxs = R / 256;                 // at least 8 K-tiles of work per split
     if (maxs < 1) maxs = 1;
     if (maxs > 4096) maxs = 4096;
     const int64_t slots = 5 * 256;
-    if (tiles * maxs <= slots) return (int)maxs;          // cannot even fill one wave: take all the parallelism there is
+    const double t_full = 2.0 * R * (double)M * N / 85e12, t_slab = 2.0 * (double)M * N * 4.0 / 3e12;
     int64_t best = 1;
-    double best_eff = 0.0;
-    for (int64_t sp = (slots + tiles - 1) / tiles; sp <= maxs && sp * tiles <= 4 * slots; ++sp) {
+    double best_t = 1e30;
+    for (int64_t sp = 1; sp <= maxs && (sp == 1 || sp * tiles <= 6 * slots); ++sp) {
         const int64_t wgs = sp * tiles, waves = (wgs + slots - 1) / slots;
-        const double eff = (double)wgs / (double)(waves * slots);
-        if (eff > best_eff + 1e-9) { best_eff = eff; best = sp; }
-        if (eff >= 0.93) return (int)sp;
+        const double t = t_full * (double)(waves * slots) / (double)wgs + (sp > 1 ? sp * t_slab : 0.0);
+        if (t < best_t - 1e-12) { best_t = t; best = sp; }
     }
     return (int)best;
 }
