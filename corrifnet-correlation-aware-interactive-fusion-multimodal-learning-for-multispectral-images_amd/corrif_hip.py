@@ -72,6 +72,10 @@ _SIGS = {
     "corrif_conv1x1_small_fwd": (i32, [ptr, i64, ptr, i32, ptr, ptr, i64, i64, i32, i32, ptr]),
     "corrif_conv1x1_small_wgrad": (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i32, i32, ptr]),
     "corrif_conv1x1_small_workspace": (C.c_size_t, [i64, i32, i32]),
+    "corrif_stem_supported": (i32, [i32] * 10),
+    "corrif_stem_fwd": (i32, [ptr, i64, ptr, ptr, i64, i32, i32, i32, i32, ptr]),
+    "corrif_stem_wgrad_workspace": (C.c_size_t, []),
+    "corrif_stem_wgrad": (i32, [ptr, i64, ptr, i64, ptr, ptr, i32, i32, i32, i32, ptr]),
     "corrif_slab_reduce": (i32, [ptr, ptr, i64, i32, ptr]),
     "corrif_col_sum": (i32, [ptr, i64, i64, i32, ptr, ptr, ptr]),
     "corrif_col_sum_workspace": (C.c_size_t, [i64, i32]),

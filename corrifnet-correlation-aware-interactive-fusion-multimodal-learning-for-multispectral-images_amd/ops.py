@@ -154,6 +154,18 @@ def conv3_patch_wgrad(x, ldx, gy, ldg, gwp, B, S, O, Ci, Co, clamp, dev):
     check(lib().corrif_conv3_patch_wgrad(q, stream()), "corrif_conv3_patch_wgrad")
 
 
+USE_STEM_KERNEL = True      # diagnostics: False routes the encoder stem (Cin = 1, 3x7x7 / (1,2,2)) through the scalar-gather implicit GEMM
+
+
+def stem_fwd(x, batch_pitch, wp, y, ldy, B, D, Hh, W):
+    check(lib().corrif_stem_fwd(P(x), batch_pitch, P(wp), P(y), ldy, B, D, Hh, W, stream()), "corrif_stem_fwd")
+
+
+def stem_wgrad(x, batch_pitch, gy, ldg, gwp, B, D, Hh, W):
+    ws = _ws(lib().corrif_stem_wgrad_workspace(), gy.device)
+    check(lib().corrif_stem_wgrad(P(x), batch_pitch, P(gy), ldg, P(gwp), P(ws), B, D, Hh, W, stream()), "corrif_stem_wgrad")
+
+
 USE_PATCH = True      # diagnostics: False routes the narrow 3x3x3 layers through the implicit-GEMM kernels instead of the patch kernels
 
 
@@ -237,7 +249,12 @@ class ConvFn(Function):
         y, _, ldc = rows_view(out)
         assert y is out, "conv output slice must be row-addressable"
         is_gemm = T == 1 and stride == (1, 1, 1) and not stem
-        if stem:
+        stem_k = stem and bias is None and act == ACT_NONE and not replicate and USE_STEM_KERNEL and \
+            lib().corrif_stem_supported(Co, kd, kh, kw, *stride, *pad)
+        if stem_k:                                # the encoder stem: patch-staged kernel for Cin = 1, 3x7x7 / (1,2,2)
+            wp = repack(weight, (Co, 148), Co, 1, T, 0, 148, zero=True)
+            stem_fwd(x, batch_pitch, wp, y, ldc, B, Di, Hi, Wi)
+        elif stem:
             Kp = (T + 3) // 4 * 4
             wp = repack(weight, (Co, Kp), Co, 1, T, 0, Kp, zero=True)
             geom = H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad, clamp=replicate, ntaps=T, src_batch_pitch=batch_pitch)
@@ -264,6 +281,7 @@ class ConvFn(Function):
                  stats=st)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, replicate, bias is not None, (B, Di, Hi, Wi), (Do, Ho, Wo), stem, is_gemm, lda, batch_pitch)
+        ctx.stem_k = bool(stem_k)
         return out
 
     @staticmethod
@@ -332,7 +350,11 @@ class ConvFn(Function):
             gx = _finish_link(ctx.grad_link, gx)
             return gx, gw, gb, None, None, None, None, None, None, None
         if ctx.needs_input_grad[1]:
-            if stem:
+            if stem and ctx.stem_k:
+                gwp = torch.empty((Co, 148), dtype=torch.float32, device=dev)
+                stem_wgrad(x, batch_pitch, gy, ldg, gwp, B, Di, Hi, Wi)
+                gw = repack(gwp, weight.shape, Co, 1, T, 2, 148)
+            elif stem:
                 Kp = (T + 3) // 4 * 4
                 gwp = torch.empty((Co, Kp), dtype=torch.float32, device=dev)
                 geom = H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad, clamp=replicate, ntaps=T, src_batch_pitch=batch_pitch)

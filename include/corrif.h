@@ -110,6 +110,18 @@ typedef struct CorrifGemm {
 int corrif_gemm_fwd(const CorrifGemm* p, void* stream);
 size_t corrif_gemm_fwd_workspace(const CorrifGemm* p);   /* bytes of CorrifGemm.ws this launch needs; queries the device's CU count */
 
+/* The encoder stem (mmvit4.py:120,172: Conv3d(1, 64, (3,7,7), stride (1,2,2), padding (1,3,3), bias=False) = inflate_conv of the
+ * ResNet-50 conv1) on one modality plane x[b] = x + b*batch_pitch of the NCDHW input ([D][H][W] floats): patch-staged MFMA kernels
+ * for the Cin = 1 case, where the implicit-GEMM loader would gather scalars.  wk / dwk: [64][148] (output channel major, the 147 taps
+ * (td, th, tw) contiguous, column 147 zero) = corrif_weight_repack mode 0 / 2 with ldo = 148; y / dy: channels-last rows of 64.
+ * ws: corrif_stem_wgrad_workspace() bytes.  corrif_stem_supported tells whether a layer has this geometry (else: corrif_gemm_fwd). */
+int corrif_stem_supported(int32_t Co, int32_t kd, int32_t kh, int32_t kw, int32_t sd, int32_t sh, int32_t sw, int32_t pd, int32_t ph, int32_t pw);
+int corrif_stem_fwd(const float* x, int64_t batch_pitch, const float* wk, float* y, int64_t ldy, int32_t B, int32_t D, int32_t H, int32_t W,
+                    void* stream);
+size_t corrif_stem_wgrad_workspace(void);
+int corrif_stem_wgrad(const float* x, int64_t batch_pitch, const float* dy, int64_t lddy, float* dwk, float* ws, int32_t B, int32_t D, int32_t H,
+                      int32_t W, void* stream);
+
 /* W-type contraction over rows:  C[z][M,N] = sum_r A[r][M] * gather(B)[r][N]     N = taps*Cs
  * Replaces aten::convolution_backward's weight gradient (A = dY, B = layer input) for every
  * conv above, the weight gradients of nn.Linear, and the P^T*dO / dS^T*Q products of the

@@ -163,8 +163,13 @@ def test_conv3d_sliced_io(ops):
     assert (out[..., :24] == 7).all() and (out[..., 48:] == 7).all()
 
 
-def test_stem_conv(ops):
-    B, D, Hh, W = 2, 3, 30, 34
+@pytest.mark.parametrize("shape", [(2, 3, 30, 34), (3, 4, 64, 64), (1, 2, 45, 19)], ids=["ragged", "full_tiles_many", "odd"])
+@pytest.mark.parametrize("stem_kernel", [True, False], ids=["patch_kernel", "scalar_gather_gemm"])
+def test_stem_conv(ops, shape, stem_kernel, monkeypatch):
+    """the encoder stem (Cin = 1, 3x7x7, stride (1,2,2)) on a strided modality plane of the NCDHW input: the patch-staged kernels and the
+    generic scalar-gather implicit GEMM they replace, against F.conv3d; ragged tiles, several tiles per persistent workgroup, odd sizes"""
+    monkeypatch.setattr(ops, "USE_STEM_KERNEL", stem_kernel)
+    B, D, Hh, W = shape
     xin = rnd(B, 3, D, Hh, W, seed=7)
     w = rnd(64, 1, 3, 7, 7, seed=8, scale=1 / 12.0)
     wr = w.clone().requires_grad_()
