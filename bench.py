@@ -223,11 +223,16 @@ def main():
         model.decoder_split = int(os.environ["CORRIF_DECODER_SPLIT"])
     if os.environ.get("CORRIF_STREAM_K") is not None:        # A/B switch: 0 = every GEMM as one workgroup per tile
         ops.STREAM_K = os.environ["CORRIF_STREAM_K"] == "1"
+    if os.environ.get("CORRIF_STREAM_K_LONG") is not None:   # A/B switch: 0 = no stream-K split for the long-K, few-tile GEMMs either
+        ops.STREAM_K_LONG = os.environ["CORRIF_STREAM_K_LONG"] == "1"
+    if os.environ.get("CORRIF_SIDE_WGRAD") is not None:      # A/B switch: 0 = the encoders' weight gradients stay on their branch stream
+        ops.SIDE_WGRAD = os.environ["CORRIF_SIDE_WGRAD"] == "1"
     if os.environ.get("CORRIF_AUTO_STREAMS") is not None:    # A/B switch: 0 = keep the multi-stream schedule whatever the memory estimate says
         model.auto_streams = os.environ["CORRIF_AUTO_STREAMS"] == "1"
     if os.environ.get("CORRIF_FLASH") is not None:           # A/B switch: 0 = materialised attention scores
         ops.FLASH_ATTENTION = os.environ["CORRIF_FLASH"] == "1"
     if os.environ.get("CORRIF_SERIAL") == "1":          # profiling aid: one stream, clean per-kernel attribution
+        ops.SIDE_WGRAD = False
         model.concurrent_branches = False
         model.decoder_fuse.concurrent_skips = False
         model.decoder_split = 0
@@ -268,6 +273,7 @@ def main():
         # region with the three modality branches serialised on one stream (with concurrent streams an event pair also
         # spans the other streams' kernels, so per-kernel durations are only meaningful one stream at a time)
         model.concurrent_branches = False
+        side_was, ops.SIDE_WGRAD = ops.SIDE_WGRAD, False
         split_was, model.decoder_split = model.decoder_split, 0
         skips_was, model.decoder_fuse.concurrent_skips = model.decoder_fuse.concurrent_skips, False
         kt_steps = min(2, args.steps)
@@ -285,6 +291,7 @@ def main():
         torch.cuda.synchronize()
         del ga, gb, gc
         model.concurrent_branches = True
+        ops.SIDE_WGRAD = side_was
         model.decoder_split = split_was
         model.decoder_fuse.concurrent_skips = skips_was
     if world > 1:

@@ -88,8 +88,11 @@ class Conv3dP(nn.Module):
         else:
             self.register_parameter("bias", None)
 
+    side_wgrad = False      # set on the encoders' convolutions (one gradient per step): ops.SIDE_WGRAD
+
     def forward(self, x, out=None, stats=None, grad_link=None):
-        return ops.conv3d(x, self.weight, self.bias, self.stride, self.pad, self.replicate, out, stats=stats, grad_link=grad_link)
+        return ops.conv3d(x, self.weight, self.bias, self.stride, self.pad, self.replicate, out, stats=stats, grad_link=grad_link,
+                          side_wgrad=self.side_wgrad)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%s, stride=%s, padding=%s%s%s" % (
@@ -527,7 +530,12 @@ class MMVit4(nn.Module):
         self.decoder_split = 2          # number of sample groups (0 / 1 = off)
         self._dec_streams = None
         self._edges = _Edges()
+        for enc in (self.RGB_encoder, self.NIR_encoder, self.SWIR_encoder):      # used once per step: weight gradients may run beside
+            for m in enc.modules():                                               # the branch's normalisation passes (ops.SIDE_WGRAD)
+                if isinstance(m, Conv3dP):
+                    m.side_wgrad = True
         self.auto_streams = True        # single-stream schedule when the step's autograd state nears the HBM capacity
+        self._mem_plan = {}             # input shape -> single-stream? (see _wants_single_stream)
 
     def flush_counters(self):
         """bring every BatchNorm's `num_batches_tracked` buffer up to date (see BatchNorm3dP)"""
@@ -558,7 +566,7 @@ class MMVit4(nn.Module):
             raise ValueError("expected fp32 input [B, 3, D, H, W]")
         B = x.shape[0]
         P3, T = patch_size, transformer_basic_dims
-        if self.auto_streams and torch.is_grad_enabled() and _memory_limited(x):
+        if self.auto_streams and torch.is_grad_enabled() and self._wants_single_stream(x):
             # Near the HBM capacity the multi-stream schedule back-fires: the caching allocator keeps one pool PER STREAM, so blocks
             # cached by one stream cannot serve another and the step degenerates into hipFree / hipMalloc retries (measured at
             # B=64, 8 bands, 256^2 = 250 GB of autograd state: 10.4 s per step on seven streams, 1.16 s on one).
@@ -569,6 +577,27 @@ class MMVit4(nn.Module):
             finally:
                 self.concurrent_branches, self.decoder_split, self.decoder_fuse.concurrent_skips = saved
         return self._forward(x)
+
+    def _wants_single_stream(self, x):
+        """Memory plan per input shape.  The first training step at a shape is scheduled from an a-priori estimate of its autograd state
+        (`_memory_limited`); every later step from the MEASURED peak of the step before it (torch.cuda.max_memory_allocated, reset at
+        each forward): multi-stream while the peak stays under 55 % of the device memory, single-stream above 75 %, no change in
+        between (the multi-stream schedule itself needs more than the single-stream one: per-stream pools)."""
+        key, dev = tuple(x.shape), x.device
+        total = torch.cuda.get_device_properties(dev).total_memory
+        plan = self._mem_plan.get(key)
+        if plan is None:
+            single = _memory_limited(x)
+        else:
+            peak = torch.cuda.max_memory_allocated(dev)
+            single = plan
+            if peak > 0.75 * total:
+                single = True
+            elif peak < 0.55 * total:
+                single = False
+        self._mem_plan[key] = single
+        torch.cuda.reset_peak_memory_stats(dev)
+        return single
 
     def _forward(self, x):
         B = x.shape[0]

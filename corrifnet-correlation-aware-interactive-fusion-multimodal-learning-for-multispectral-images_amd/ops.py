@@ -59,6 +59,9 @@ def _ws(nbytes, dev):
 # a loss in wall time (304.9 vs 300.7 ms per step): the branch streams already fill the tails, short-K shapes pay more for the slab
 # round trip than they gain, and every launch costs a second descriptor call on the host.
 STREAM_K = False
+# STREAM_K_LONG restricts it to where it helps a launch in isolation: long K loops on a small tile grid (e4 / e5's 3x3 convolutions and
+# their data gradients: 392 / 196 tiles of 128 x 128 on 512 slots, 72 / 144 K tiles; 84 -> 98 TFLOP/s alone, tools/gemm_lab.hip).
+STREAM_K_LONG = False     # measured (round 2): wall-neutral on the B=32 step (248.4 vs 248.0 ms), the branch streams already fill those tails
 
 
 def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, addend=None, ld_add=0, act=ACT_NONE,
@@ -87,9 +90,10 @@ def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, add
     g.sB_o, g.sB_i = sB
     g.sC_o, g.sC_i = sC
     g.g = geom
-    g.no_split = 0 if STREAM_K else 1
     buf = None
-    if STREAM_K:
+    sk = STREAM_K or (STREAM_K_LONG and K >= 2048 and Z == 1 and M * N <= 128 * 128 * 512)
+    g.no_split = 0 if sk else 1
+    if sk:
         nws = lib().corrif_gemm_fwd_workspace(g)      # stream-K split: slabs for the tiles a share boundary cuts
         if nws:
             buf = _ws(nws, torch.device("cuda", torch.cuda.current_device()))
@@ -224,12 +228,63 @@ def _out_size(i, k, s, p):
 
 
 # --------------------------------------------------------------------------------------- convolution
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+# ---- weight gradients on a side stream -------------------------------------------------------------------------------------------
+# A convolution's weight gradient is off the backward's critical path (nothing downstream reads it before the optimiser), while the
+# BatchNorm backward passes that follow it on the same branch stream are HBM-bound: with the weight-gradient GEMM on a side stream of the
+# branch, the matrix pipe stays busy under those passes (round 2 timeline: 30 ms of the step had only normalisation kernels resident).
+# Only for parameters that receive exactly one gradient per step and whose .grad is None (autograd then just adopts the tensor - no
+# accumulation kernel could race with the side stream); every side stream is joined into the default stream by an autograd-engine
+# callback at the end of the backward pass.  Measured (round 2, one box, alternating runs): 251.1 ms per step with it, 250.7 without -
+# the normalisation passes and the weight gradients share the CUs either way - so it is OFF; kept as a switch.
+SIDE_WGRAD = False
+_side_streams = {}            # id of the stream a backward node runs on -> (side stream, event pool, cursor)
+_side_pending = {"queued": False}
+
+
+def _side_join():
+    _side_pending["queued"] = False
+    cur = torch.cuda.current_stream()
+    for st, _, _ in _side_streams.values():
+        cur.wait_stream(st)
+
+
+def _side_begin(tensors):
+    """side stream of the current stream, ordered after everything enqueued on the current stream so far; `tensors` are read there"""
+    main = torch.cuda.current_stream()
+    ent = _side_streams.get(main.cuda_stream)
+    if ent is None:
+        ent = _side_streams[main.cuda_stream] = [torch.cuda.Stream(), [], 0]
+    side, pool, i = ent
+    if i == len(pool):
+        pool.append(torch.cuda.Event())
+    ev = pool[i]
+    ent[2] = (i + 1) % 64                     # ring of persistent events (an event is re-recorded long after its wait was enqueued)
+    ev.record(main)
+    side.wait_event(ev)
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    if not _side_pending["queued"]:
+        _side_pending["queued"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_side_join)
+    return side
+
+
 class ConvFn(Function):
     """nn.Conv3d on channels-last activations.  weight stays in the reference (O,I,kd,kh,kw) layout."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, replicate, out, act, stats_req, grad_link=None):
+    def forward(ctx, x, weight, bias, stride, pad, replicate, out, act, stats_req, grad_link=None, side_ok=False):
         ctx.grad_link = grad_link
+        ctx.side_ok = side_ok
         Co, Ci, kd, kh, kw = weight.shape
         T = kd * kh * kw
         stem = Ci == 1
@@ -348,7 +403,21 @@ class ConvFn(Function):
             ws = _ws(lib().corrif_conv1x1_small_workspace(M, Ci, Co), dev)
             check(lib().corrif_conv1x1_small_wgrad(P(x), lda, P(gy), ldg, P(gw), P(gb), P(ws), M, Ci, Co, stream()), "corrif_conv1x1_small_wgrad")
             gx = _finish_link(ctx.grad_link, gx)
-            return gx, gw, gb, None, None, None, None, None, None, None
+            return gx, gw, gb, None, None, None, None, None, None, None, None
+        side = None
+        if SIDE_WGRAD and ctx.side_ok and ctx.needs_input_grad[1] and weight.grad is None and not torch.cuda.is_current_stream_capturing():
+            side = _side_begin((gy, x))
+        with torch.cuda.stream(side) if side is not None else _NullCtx():
+            gw, gb = ConvFn._weight_grads(ctx, x, weight, gy, M, ldg, dev)
+        gx = _finish_link(ctx.grad_link, gx)
+        return gx, gw, gb, None, None, None, None, None, None, None, None
+
+    @staticmethod
+    def _weight_grads(ctx, x, weight, gy, M, ldg, dev):
+        stride, pad, replicate, has_bias, (B, Di, Hi, Wi), (Do, Ho, Wo), stem, is_gemm, lda, batch_pitch = ctx.cfg
+        Co, Ci, kd, kh, kw = weight.shape
+        T = kd * kh * kw
+        gw = gb = None
         if ctx.needs_input_grad[1]:
             if stem and ctx.stem_k:
                 gwp = torch.empty((Co, 148), dtype=torch.float32, device=dev)
@@ -374,8 +443,7 @@ class ConvFn(Function):
                 gw = repack(gwp, weight.shape, Co, Ci, T, 2, T * Ci)
         if has_bias and ctx.needs_input_grad[2]:
             gb = col_sum(gy, M, ldg, Co)
-        gx = _finish_link(ctx.grad_link, gx)
-        return gx, gw, gb, None, None, None, None, None, None, None
+        return gw, gb
 
 
 TAP_STATS = {"epilogue": 0, "added": 0, "late": 0}      # grad_tap bookkeeping (tests): absorbed by a GEMM epilogue / own add pass / missed
@@ -418,10 +486,11 @@ def grad_tap(x, link):
     return GradTapFn.apply(x, link)
 
 
-def conv3d(x, weight, bias=None, stride=(1, 1, 1), pad=(0, 0, 0), replicate=False, out=None, act=ACT_NONE, stats=None, grad_link=None):
+def conv3d(x, weight, bias=None, stride=(1, 1, 1), pad=(0, 0, 0), replicate=False, out=None, act=ACT_NONE, stats=None, grad_link=None,
+           side_wgrad=False):
     """stats: None, or a dict {"G": groups, "relu": bool}: ask the GEMM epilogue for the statistics partials of the norm that follows;
     on success the dict gains "part" / "chunks" / "rpg" (pass it to batch_norm / relu_instnorm as `pre`)."""
-    return ConvFn.apply(x, weight, bias, tuple(stride), tuple(pad), bool(replicate), out, act, stats, grad_link)
+    return ConvFn.apply(x, weight, bias, tuple(stride), tuple(pad), bool(replicate), out, act, stats, grad_link, bool(side_wgrad))
 
 
 class SplitWeightFn(Function):
