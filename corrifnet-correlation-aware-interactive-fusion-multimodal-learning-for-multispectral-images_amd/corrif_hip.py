@@ -34,7 +34,8 @@ class Gemm(C.Structure):
                 ("out_map", i32), ("OD", i32), ("OH", i32), ("OW", i32), ("om_d", i32), ("om_h", i32), ("om_w", i32),
                 ("oo_d", i32), ("oo_h", i32), ("oo_w", i32),
                 ("stats_part", ptr), ("stats_rows_per_group", i64), ("stats_relu", i32), ("ws", ptr), ("no_split", i32),
-                ("addend2", ptr), ("ld_add2", i64)]
+                ("addend2", ptr), ("ld_add2", i64),
+                ("bstats_x", ptr), ("bstats_ldx", i64), ("bstats_y", ptr), ("bstats_ldy", i64), ("bstats_mean", ptr), ("bstats_rstd", ptr)]
 
 
 class Wgrad(C.Structure):
@@ -85,6 +86,7 @@ _SIGS = {
     "corrif_norm_eval_rstd": (i32, [ptr, f32, ptr, i32, ptr]),
     "corrif_norm_apply": (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, i64, i64, i32, i32, i32, ptr]),
     "corrif_norm_bwd": (i32, [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, ptr, i64, i32, i32, i32, i32, ptr, ptr]),
+    "corrif_norm_bwd_pre": (i32, [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, ptr, i64, i32, i32, ptr, i32, ptr, ptr]),
     "corrif_norm_workspace": (C.c_size_t, [i64, i32, i32]),
     "corrif_layernorm_fwd": (i32, [ptr, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, f32, ptr]),
     "corrif_layernorm_bwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr]),
@@ -148,7 +150,7 @@ def lib():
             fn = getattr(l, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if l.corrif_abi_version() != 4:
+        if l.corrif_abi_version() != 5:
             raise RuntimeError("corrif: ABI version mismatch")
         _lib = l
     return _lib

@@ -246,6 +246,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
             if (col + e < p.N) bv[e] = p.bias[col + e];
     }
     double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};      // fused norm statistics of this lane's 4 columns (double: no cancellation loss)
+    f32x4 bmu = {0.f, 0.f, 0.f, 0.f}, brs = {0.f, 0.f, 0.f, 0.f};      // backward-statistics mode: mean / rstd of this lane's 4 columns
+    if (p.bs_x) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (col + e < p.N) { bmu[e] = p.bs_mean[col + e]; brs[e] = p.bs_rstd[col + e]; }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -261,7 +267,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
             f32x4 v = *reinterpret_cast<const f32x4*>(&stg[lr * SP + cq * 4]);
             if (row >= p.M || col >= p.N) continue;
             v += bv;
-            if (p.stats_part) {
+            if (p.stats_part && !p.bs_x) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const double sv = (double)(p.stats_relu ? fmaxf(v[e], 0.f) : v[e]);
@@ -288,6 +294,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
                 }
+                if (p.bs_x) {      // v is the complete gradient w.r.t. the producing BatchNorm's output (addends included)
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(p.bs_x + (int64_t)row * p.bs_ldx + col);
+                    f32x4 yv = {1.f, 1.f, 1.f, 1.f};
+                    if (p.bs_y) yv = *reinterpret_cast<const f32x4*>(p.bs_y + (int64_t)row * p.bs_ldy + col);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gm = yv[e] > 0.f ? v[e] : 0.f;
+                        const float xh = (xv[e] - bmu[e]) * brs[e];
+                        ssum[e] += (double)gm;
+                        ssq[e] += (double)gm * (double)xh;
+                    }
+                }
                 *reinterpret_cast<f32x4*>(dst) = v;
             } else {
 #pragma unroll
@@ -298,6 +316,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
                     if (p.addend2) x += p.addend2[(int64_t)row * p.ld_add2 + col + e];
                     if (p.act == CORRIF_ACT_RELU) x = fmaxf(x, 0.f);
                     else if (p.act == CORRIF_ACT_GELU) x = gelu_erf(x);
+                    if (p.bs_x) {
+                        const float yv = p.bs_y ? p.bs_y[(int64_t)row * p.bs_ldy + col + e] : 1.f;
+                        const float gm = yv > 0.f ? x : 0.f;
+                        ssum[e] += (double)gm;
+                        ssq[e] += (double)gm * (double)((p.bs_x[(int64_t)row * p.bs_ldx + col + e] - bmu[e]) * brs[e]);
+                    }
                     dst[e] = x;
                 }
             }
@@ -551,6 +575,11 @@ static int gemm_fwd_impl(const CorrifGemm* p, void* stream, bool plan_only, size
     a.ntap_sel = p->ntap_sel;
     for (int i = 0; i < 28; ++i) a.tap_sel[i] = p->tap_sel[i];
     a.stats_part = p->stats_part; a.stats_relu = p->stats_relu; a.stats_rpg = 1; a.stats_chunks = 1;
+    a.bs_x = p->bstats_x; a.bs_ldx = p->bstats_ldx; a.bs_y = p->bstats_y; a.bs_ldy = p->bstats_ldy; a.bs_mean = p->bstats_mean; a.bs_rstd = p->bstats_rstd;
+    if (p->bstats_x) {
+        if (!p->stats_part || !p->bstats_mean || !p->bstats_rstd || p->bstats_ldx < p->N || (p->bstats_y && p->bstats_ldy < p->N)) return CORRIF_EINVAL;
+        if ((p->bstats_ldx & 3) || (p->bstats_ldy & 3) || ((uintptr_t)p->bstats_x & 15) || ((uintptr_t)p->bstats_y & 15)) return CORRIF_EUNSUPPORTED;
+    }
     if (p->stats_part) {
         if (p->Z != 1 || p->stats_rows_per_group <= 0 || p->stats_rows_per_group > p->M || (p->M % p->stats_rows_per_group)) return CORRIF_EINVAL;
         if (p->stats_rows_per_group != p->M && (p->stats_rows_per_group & 63)) return CORRIF_EUNSUPPORTED;

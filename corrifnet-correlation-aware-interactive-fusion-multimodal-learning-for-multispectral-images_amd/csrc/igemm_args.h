@@ -18,6 +18,9 @@ struct GemmArgs {
     // sk_ws[2 * G][BM * BN]; sk_tiles = sk_tiles_mn * Z
     float* sk_ws; int sk_G, sk_nk, sk_tiles, sk_tiles_mn, sk_allowed;
     const float* addend2; int64_t ld_add2;      // second epilogue addend (a tensor with three consumers: two gradients ride along)
+    // backward statistics of the BatchNorm that produced this GEMM's input (data-gradient launches): with bs_x set, stats_part receives
+    // per column and 64-row block (sum g', sum g' * xhat), g' = the value this epilogue stores masked by bs_y > 0, xhat = (bs_x - mean) * rstd
+    const float* bs_x; int64_t bs_ldx; const float* bs_y; int64_t bs_ldy; const float* bs_mean; const float* bs_rstd;
 };
 
 

@@ -350,6 +350,29 @@ extern "C" int corrif_norm_bwd(const float* dy, int64_t lddy, const float* y, in
     return CORRIF_OK;
 }
 
+extern "C" int corrif_norm_bwd_pre(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx, const float* mean,
+                                   const float* rstd, const float* gamma, float* dx, int64_t lddx, float* dres, int64_t lddres, float* dgamma,
+                                   float* dbeta, int64_t rows, int32_t C, int32_t flags, const double* part, int32_t chunks, double* ws,
+                                   void* stream) {
+    if (!dy || !x || !mean || !rstd || !part || chunks <= 0 || !ws || !norm_args_ok(rows, 1, C)) return CORRIF_EINVAL;
+    if ((flags & CORRIF_NORM_RELU_OUT) && !y) return CORRIF_EINVAL;
+    if ((lddy & 3) || (ldy & 3) || (ldx & 3) || (lddx & 3) || (lddres & 3) || !al16(dy) || !al16(y) || !al16(x) || !al16(dx) ||
+        !al16(dres) || !al16(mean) || !al16(rstd) || !al16(gamma))
+        return CORRIF_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    float* sums = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(norm_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, (int)chunks, 1, (int)C, sums, dgamma, dbeta, (float*)nullptr);
+    CORRIF_CHECK_LAUNCH();
+    if (dx || dres) {
+        int nblk, ctiles;
+        ApplyGeo a = apply_geo(rows, C, nblk, ctiles);
+        hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(nblk, ctiles, 1), dim3(256), 0, s, dy, lddy, y, ldy, x, ldx, mean, rstd, gamma,
+                           (const float*)sums, dx, lddx, dres, lddres, rows, (int)C, (int)flags, 0, a);
+        CORRIF_CHECK_LAUNCH();
+    }
+    return CORRIF_OK;
+}
+
 // column sums (bias gradients): the statistics partial pass (sum, sum^2) + the wave-per-channel final
 extern "C" size_t corrif_col_sum_workspace(int64_t rows, int32_t C) { return corrif_norm_workspace(rows, 1, C); }
 extern "C" int corrif_col_sum(const float* x, int64_t ld, int64_t rows, int32_t C, float* out, double* ws, void* stream) {

@@ -90,9 +90,9 @@ class Conv3dP(nn.Module):
 
     side_wgrad = False      # set on the encoders' convolutions (one gradient per step): ops.SIDE_WGRAD
 
-    def forward(self, x, out=None, stats=None, grad_link=None):
+    def forward(self, x, out=None, stats=None, grad_link=None, bwd_stats=None):
         return ops.conv3d(x, self.weight, self.bias, self.stride, self.pad, self.replicate, out, stats=stats, grad_link=grad_link,
-                          side_wgrad=self.side_wgrad)
+                          side_wgrad=self.side_wgrad, bwd_stats=bwd_stats)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%s, stride=%s, padding=%s%s%s" % (
@@ -131,11 +131,11 @@ class BatchNorm3dP(nn.Module):
         self._nbt_pending = 0                      # the loaded counter replaces whatever was pending
         return super()._load_from_state_dict(*a, **kw)
 
-    def forward(self, x, residual=None, relu_in=False, relu_out=False, out=None, pre=None):
+    def forward(self, x, residual=None, relu_in=False, relu_out=False, out=None, pre=None, bwd_link=None):
         if self.training:
             self._nbt_pending += 1
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, residual, relu_in, relu_out,
-                              self.training, self.momentum, self.eps, out, pre)
+                              self.training, self.momentum, self.eps, out, pre, bwd_link)
 
     def extra_repr(self):
         return "%d, eps=%g, momentum=%g" % (self.weight.numel(), self.eps, self.momentum)
@@ -214,16 +214,25 @@ class Bottleneck3D(nn.Module):
         if link is None and GRAD_TAP and torch.is_grad_enabled() and x.requires_grad:
             link = {}          # x feeds conv1 AND the residual add / the downsample conv: conv1's data-gradient epilogue absorbs their gradient
         s1, s2, s3 = st(), st(), st()
-        y = self.bn1(self.conv1(x, stats=s1, grad_link=link), relu_out=True, pre=s1)
-        y = self.bn2(self.conv2(y, stats=s2), relu_out=True, pre=s2)
-        y = self.conv3(y, stats=s3)
+        # backward statistics of a BatchNorm come out of the data-gradient epilogue of the convolution that consumes its output
+        # (ops._bwd_stats_request): bn1 -> conv2, bn2 -> conv3, and the previous block's bn3 -> this block's conv1 when every other consumer
+        # of the block input rides on conv1's gradient link
+        tr = train and torch.is_grad_enabled()
+        l1, l2, l3 = ({} if tr else None), ({} if tr else None), ({} if tr else None)
+        prev = getattr(x, "_corrif_bn_link", None) if link is not None else None
+        y = self.bn1(self.conv1(x, stats=s1, grad_link=link, bwd_stats=prev), relu_out=True, pre=s1, bwd_link=l1)
+        y = self.bn2(self.conv2(y, stats=s2, bwd_stats=l1), relu_out=True, pre=s2, bwd_link=l2)
+        y = self.conv3(y, stats=s3, bwd_stats=l2)
         xt = x if link is None else ops.grad_tap(x, link)      # created after conv1..conv3's nodes: its backward runs before theirs
         if self.downsample is not None:                        # (the downsample path's nodes too: they are created here, not first)
             s0 = st()
             idt = self.downsample[1](self.downsample[0](xt, stats=s0), pre=s0)
         else:
             idt = xt
-        return self.bn3(y, residual=idt, relu_out=True, pre=s3)
+        out = self.bn3(y, residual=idt, relu_out=True, pre=s3, bwd_link=l3)
+        if l3 is not None:
+            out._corrif_bn_link = l3         # read by the next block's conv1 (same tensor object)
+        return out
 
 
 class _ResLayer(nn.Sequential):

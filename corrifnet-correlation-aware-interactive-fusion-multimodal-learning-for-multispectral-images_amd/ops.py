@@ -65,7 +65,7 @@ STREAM_K_LONG = False     # measured (round 2): wall-neutral on the B=32 step (2
 
 
 def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, addend=None, ld_add=0, act=ACT_NONE,
-         Z=1, Zi=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), taps=None, out_map=None, stats=None, addend2=None, ld_add2=0):
+         Z=1, Zi=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), taps=None, out_map=None, stats=None, addend2=None, ld_add2=0, bstats=None):
     g = H.Gemm()
     if stats is not None:
         g.stats_part, g.stats_rows_per_group, g.stats_relu = stats
@@ -84,6 +84,8 @@ def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, add
     g.ld_add = ld_add
     g.addend2 = addend2 if addend2 is not None else None
     g.ld_add2 = ld_add2
+    if bstats is not None:
+        g.bstats_x, g.bstats_ldx, g.bstats_y, g.bstats_ldy, g.bstats_mean, g.bstats_rstd = bstats
     g.M, g.N, g.K, g.act = M, N, K, act
     g.Z, g.Zi = Z, Zi
     g.sA_o, g.sA_i = sA
@@ -228,6 +230,25 @@ def _out_size(i, k, s, p):
 
 
 # --------------------------------------------------------------------------------------- convolution
+BWD_STATS = True      # diagnostics / A-B: False keeps the separate reduction pass of every BatchNorm backward
+
+
+def _bwd_stats_request(bl, grad_link, rows, C, dev, xin, ldin):
+    """Backward statistics of the BatchNorm that produced this convolution's input, out of the data-gradient GEMM's epilogue
+    (CorrifGemm.bstats_*): possible when this GEMM's stored value IS the complete gradient of that BatchNorm's output - the input has no
+    other consumer, or all of them parked their gradients on `grad_link` and the epilogue absorbed every one.  Returns (stats, bstats)
+    for ops.gemm and leaves the partial buffer in the BatchNorm's link."""
+    if not BWD_STATS or bl is None or "x" not in bl or bl["rows"] != rows or bl["C"] != C or C <= 16:
+        return None, None
+    if grad_link is not None and (grad_link.get("gs") or grad_link.get("late")):
+        return None, None                     # a parked gradient was left for an add pass, or a consumer already fell back to autograd
+    chunks = (rows + 63) // 64
+    part = torch.empty(C * chunks * 2, dtype=torch.float64, device=dev)
+    bl["part"], bl["chunks"], bl["grad_link"] = part, chunks, grad_link
+    # the ReLU mask of that BatchNorm is its output = this convolution's own input (kept out of the link: no reference cycle)
+    return (part.data_ptr(), rows, 0), (P(bl["x"]), bl["ldx"], P(xin) if bl["relu_out"] else None, ldin, P(bl["mean"]), P(bl["rstd"]))
+
+
 class _NullCtx:
     def __enter__(self):
         return None
@@ -282,9 +303,10 @@ class ConvFn(Function):
     """nn.Conv3d on channels-last activations.  weight stays in the reference (O,I,kd,kh,kw) layout."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, replicate, out, act, stats_req, grad_link=None, side_ok=False):
+    def forward(ctx, x, weight, bias, stride, pad, replicate, out, act, stats_req, grad_link=None, side_ok=False, bwd_stats=None):
         ctx.grad_link = grad_link
         ctx.side_ok = side_ok
+        ctx.bwd_stats = bwd_stats
         Co, Ci, kd, kh, kw = weight.shape
         T = kd * kh * kw
         stem = Ci == 1
@@ -364,8 +386,9 @@ class ConvFn(Function):
                     adds.append((ga, ld_a))
                     TAP_STATS["epilogue"] += 1
                 adds += [(None, 0)] * (2 - len(adds))
+                st, bst = _bwd_stats_request(ctx.bwd_stats, link, Min, Ci, dev, x, lda)
                 gemm(P(gy), ldg, P(weight), Ci, 1, P(gx), Ci, Min, Ci, Co, Co, H.gemm_geom(), addend=P(adds[0][0]) if adds[0][0] is not None else None,
-                     ld_add=adds[0][1], addend2=P(adds[1][0]) if adds[1][0] is not None else None, ld_add2=adds[1][1])
+                     ld_add=adds[0][1], addend2=P(adds[1][0]) if adds[1][0] is not None else None, ld_add2=adds[1][1], stats=st, bstats=bst)
             elif _patch_cc((kd, kh, kw), stride, pad, Co, Ci):      # data gradient = patch conv of dY with flipped weights
                 cc = _patch_cc((kd, kh, kw), stride, pad, Co, Ci)
                 wd = repack(weight, (Co // cc, Ci, T, cc), Co, Ci, T, 4, cc)
@@ -395,7 +418,8 @@ class ConvFn(Function):
                     _dgrad_parity_classes(gy, ldg, wd, gx, B, (Di, Hi, Wi), (Do, Ho, Wo), (kd, kh, kw), stride, pad, Ci, Co)
                 else:
                     geom = H.conv_geom((Di, Hi, Wi), (Do, Ho, Wo), (kd, kh, kw), stride, pad, transposed=True)
-                    gemm(P(gy), ldg, P(wd), Ci, 1, P(gx), Ci, Min, Ci, T * Co, Co, geom)
+                    st, bst = _bwd_stats_request(ctx.bwd_stats, ctx.grad_link, Min, Ci, dev, x, lda)
+                    gemm(P(gy), ldg, P(wd), Ci, 1, P(gx), Ci, Min, Ci, T * Co, Co, geom, stats=st, bstats=bst)
         small11 = is_gemm and lib().corrif_conv1x1_small_supported(Ci, Co)
         if small11 and ctx.needs_input_grad[1]:      # weight and bias gradient in one streaming pass
             gw = torch.empty(weight.shape, dtype=torch.float32, device=dev)
@@ -403,14 +427,14 @@ class ConvFn(Function):
             ws = _ws(lib().corrif_conv1x1_small_workspace(M, Ci, Co), dev)
             check(lib().corrif_conv1x1_small_wgrad(P(x), lda, P(gy), ldg, P(gw), P(gb), P(ws), M, Ci, Co, stream()), "corrif_conv1x1_small_wgrad")
             gx = _finish_link(ctx.grad_link, gx)
-            return gx, gw, gb, None, None, None, None, None, None, None, None
+            return gx, gw, gb, None, None, None, None, None, None, None, None, None
         side = None
         if SIDE_WGRAD and ctx.side_ok and ctx.needs_input_grad[1] and weight.grad is None and not torch.cuda.is_current_stream_capturing():
             side = _side_begin((gy, x))
         with torch.cuda.stream(side) if side is not None else _NullCtx():
             gw, gb = ConvFn._weight_grads(ctx, x, weight, gy, M, ldg, dev)
         gx = _finish_link(ctx.grad_link, gx)
-        return gx, gw, gb, None, None, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None, None
 
     @staticmethod
     def _weight_grads(ctx, x, weight, gy, M, ldg, dev):
@@ -477,6 +501,7 @@ class GradTapFn(Function):
     def backward(ctx, g):
         if ctx.link.get("done"):
             TAP_STATS["late"] += 1
+            ctx.link["late"] = True           # the absorbing GEMM's epilogue did not see this gradient (see _bwd_stats_request)
             return g, None
         ctx.link.setdefault("gs", []).append(g)
         return None, None
@@ -487,10 +512,10 @@ def grad_tap(x, link):
 
 
 def conv3d(x, weight, bias=None, stride=(1, 1, 1), pad=(0, 0, 0), replicate=False, out=None, act=ACT_NONE, stats=None, grad_link=None,
-           side_wgrad=False):
+           side_wgrad=False, bwd_stats=None):
     """stats: None, or a dict {"G": groups, "relu": bool}: ask the GEMM epilogue for the statistics partials of the norm that follows;
     on success the dict gains "part" / "chunks" / "rpg" (pass it to batch_norm / relu_instnorm as `pre`)."""
-    return ConvFn.apply(x, weight, bias, tuple(stride), tuple(pad), bool(replicate), out, act, stats, grad_link, bool(side_wgrad))
+    return ConvFn.apply(x, weight, bias, tuple(stride), tuple(pad), bool(replicate), out, act, stats, grad_link, bool(side_wgrad), bwd_stats)
 
 
 class SplitWeightFn(Function):
@@ -596,11 +621,14 @@ def _norm_ws(rows_per_group, G, C, dev):
     return _ws(lib().corrif_norm_workspace(rows_per_group, G, C), dev)
 
 
+NORM_BWD_STATS = {"epilogue": 0, "pass": 0}      # BatchNorm backwards whose reduction came from a GEMM epilogue / ran as its own pass (tests)
+
+
 class BatchNormFn(Function):
     """y = act_out(gamma * (x' - mean) * rstd + beta + residual), x' = relu(x) if relu_in.  Statistics over all rows."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, flags, training, momentum, eps, out, pre):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, flags, training, momentum, eps, out, pre, bwd_link=None):
         x, rows, ldx = rows_view(x)
         C = x.shape[-1]
         dev = x.device
@@ -629,6 +657,11 @@ class BatchNormFn(Function):
                                       stream()), "corrif_norm_apply")
         ctx.save_for_backward(x, mean, rstd, gamma, y if (flags & NORM_RELU_OUT) else None)
         ctx.cfg = (flags, not training, residual is not None)
+        ctx.bwd_link = None
+        if bwd_link is not None and training and not (flags & NORM_RELU_IN) and ldy == C:
+            # whoever consumes `out` may compute this layer's backward statistics in its data-gradient epilogue (_bwd_stats_request)
+            bwd_link.update(x=x, ldx=ldx, relu_out=bool(flags & NORM_RELU_OUT), mean=mean, rstd=rstd, rows=rows, C=C)
+            ctx.bwd_link = bwd_link
         return out
 
     @staticmethod
@@ -646,16 +679,25 @@ class BatchNormFn(Function):
         gres = torch.empty(x.shape, dtype=torch.float32, device=dev) if (has_res and ctx.needs_input_grad[5]) else None
         ggamma = torch.empty(C, dtype=torch.float32, device=dev)
         gbeta = torch.empty(C, dtype=torch.float32, device=dev)
-        ws = _norm_ws(rows, 1, C, dev)
-        check(lib().corrif_norm_bwd(P(gy), ldg, P(y), ldy, P(x), ldx, P(mean), P(rstd), P(gamma), P(gx), C, P(gres), C,
-                                    P(ggamma), P(gbeta), rows, 1, C, flags, 1 if frozen else 0, P(ws), stream()), "corrif_norm_bwd")
-        return gx, ggamma, gbeta, None, None, gres, None, None, None, None, None, None
+        bl = ctx.bwd_link
+        if bl is not None and "part" in bl and not frozen and not (bl.get("grad_link") or {}).get("late") and ldg == C:
+            # the reduction (sum g', sum g' xhat) came out of the epilogue of the data-gradient GEMM that produced gy
+            ws = torch.empty(2 * C + 16, dtype=torch.float32, device=dev)
+            check(lib().corrif_norm_bwd_pre(P(gy), ldg, P(y), ldy, P(x), ldx, P(mean), P(rstd), P(gamma), P(gx), C, P(gres), C, P(ggamma), P(gbeta),
+                                            rows, C, flags, P(bl.pop("part")), bl["chunks"], P(ws), stream()), "corrif_norm_bwd_pre")
+            NORM_BWD_STATS["epilogue"] += 1
+        else:
+            ws = _norm_ws(rows, 1, C, dev)
+            check(lib().corrif_norm_bwd(P(gy), ldg, P(y), ldy, P(x), ldx, P(mean), P(rstd), P(gamma), P(gx), C, P(gres), C,
+                                        P(ggamma), P(gbeta), rows, 1, C, flags, 1 if frozen else 0, P(ws), stream()), "corrif_norm_bwd")
+            NORM_BWD_STATS["pass"] += 1
+        return gx, ggamma, gbeta, None, None, gres, None, None, None, None, None, None, None
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, residual=None, relu_in=False, relu_out=False, training=True,
-               momentum=0.1, eps=1e-5, out=None, pre=None):
+               momentum=0.1, eps=1e-5, out=None, pre=None, bwd_link=None):
     flags = (NORM_RELU_IN if relu_in else 0) | (NORM_RELU_OUT if relu_out else 0)
-    return BatchNormFn.apply(x, gamma, beta, running_mean, running_var, residual, flags, training, momentum, eps, out, pre)
+    return BatchNormFn.apply(x, gamma, beta, running_mean, running_var, residual, flags, training, momentum, eps, out, pre, bwd_link)
 
 
 class ReluInstNormFn(Function):

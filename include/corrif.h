@@ -32,7 +32,7 @@ extern "C" {
 #define CORRIF_EUNSUPPORTED (-2)
 #define CORRIF_ELAUNCH (-3)
 
-#define CORRIF_ABI_VERSION 4   /* 2: CorrifConv3Patch.fold  3: CorrifGemm.ws / no_split (stream-K), corrif_scale, corrif_fill  4: CorrifGemm.addend2, corrif_flash_attn_* */
+#define CORRIF_ABI_VERSION 5   /* 2: CorrifConv3Patch.fold  3: CorrifGemm.ws / no_split (stream-K), corrif_scale, corrif_fill  4: CorrifGemm.addend2, corrif_flash_attn_*  5: CorrifGemm.bstats_*, corrif_norm_bwd_pre, corrif_stem_*, corrif_depth_* */
 int corrif_abi_version(void);
 /* name of the gfx target the library was built for ("gfx950") - host-only call */
 const char* corrif_build_arch(void);
@@ -106,6 +106,12 @@ typedef struct CorrifGemm {
      * 1x1x1 convolution whose input has three consumers (a ResNet layer output feeds the next block's conv1, its downsample conv and
      * the encoder's adapt conv, mmvit4.py:176-186,204-212): the other two gradients ride along instead of two accumulation passes. */
     const float* addend2; int64_t ld_add2;
+    /* backward statistics of a BatchNorm in the epilogue of the data-gradient GEMM that produces the gradient of its output (ABI 5;
+     * mmvit4.py:204-212: conv -> BN -> ReLU -> conv): with bstats_x set, stats_part receives per column and 64-row block
+     * (sum g', sum g' * xhat) instead of the forward statistics, g' = the stored value (addends included) where bstats_y > 0 (NULL: no
+     * ReLU after that BatchNorm) and xhat = (bstats_x - bstats_mean) * bstats_rstd; bstats_x / bstats_y are [M][N] like C.
+     * corrif_norm_bwd_pre consumes the partials: the separate reduction pass over (dy, x, y) of corrif_norm_bwd disappears. */
+    const float* bstats_x; int64_t bstats_ldx; const float* bstats_y; int64_t bstats_ldy; const float* bstats_mean; const float* bstats_rstd;
 } CorrifGemm;
 int corrif_gemm_fwd(const CorrifGemm* p, void* stream);
 size_t corrif_gemm_fwd_workspace(const CorrifGemm* p);   /* bytes of CorrifGemm.ws this launch needs; queries the device's CU count */
@@ -234,6 +240,11 @@ int corrif_norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, 
                     const float* mean, const float* rstd, const float* gamma,
                     float* dx, int64_t lddx, float* dres, int64_t lddres, float* dgamma, float* dbeta,
                     int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, int32_t frozen, double* ws, void* stream);
+/* the same with the reduction already done: part = per-(channel, 64-row block) partials (sum g', sum g' * xhat) written by the epilogue of
+ * the data-gradient GEMM that produced dy (CorrifGemm.bstats_*), chunks blocks per channel; G = 1 (BatchNorm).  ws: corrif_norm_workspace. */
+int corrif_norm_bwd_pre(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx, const float* mean,
+                        const float* rstd, const float* gamma, float* dx, int64_t lddx, float* dres, int64_t lddres, float* dgamma,
+                        float* dbeta, int64_t rows, int32_t C, int32_t flags, const double* part, int32_t chunks, double* ws, void* stream);
 size_t corrif_norm_workspace(int64_t rows_per_group, int32_t G, int32_t C);
 
 /* LayerNorm over the last dim (C = 512), eps 1e-5 (mmvit4.py:327,335; aten::native_layer_norm).

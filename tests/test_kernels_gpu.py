@@ -148,6 +148,47 @@ def test_gemm_stream_k_split(ops, cfg):
     assert rel(c1, c0) < 1e-6
 
 
+@pytest.mark.parametrize("kind", ["1x1", "1x3x3"])
+def test_batch_norm_backward_statistics_from_dgrad_epilogue(ops, kind, monkeypatch):
+    """conv -> BatchNorm(train) -> ReLU -> conv: the second convolution's data-gradient GEMM epilogue produces (sum g', sum g' xhat) of the
+    BatchNorm backward (CorrifGemm.bstats_*, corrif_norm_bwd_pre); same gradients as with the separate reduction pass and as stock ATen."""
+    B, D, Hh, W, Ci, Cm, Co = 2, 3, 10, 12, 32, 48, 64
+    x = rnd(B, Ci, D, Hh, W, seed=1)
+    w1 = rnd(Cm, Ci, 1, 1, 1, seed=2, scale=0.2)
+    k2 = (1, 1, 1) if kind == "1x1" else (1, 3, 3)
+    p2 = (0, 0, 0) if kind == "1x1" else (0, 1, 1)
+    w2 = rnd(Co, Cm, *k2, seed=3, scale=0.1)
+    gamma, beta = rnd(Cm, seed=4).abs() + 0.5, rnd(Cm, seed=5)
+    go = rnd(B, Co, D, Hh, W, seed=6)
+    ref = [t.clone().requires_grad_() for t in (x, w1, w2, gamma, beta)]
+    h = F.relu(F.batch_norm(F.conv3d(ref[0], ref[1]), None, None, ref[3], ref[4], True, 0.1, 1e-5))
+    F.conv3d(h, ref[2], None, 1, p2).backward(go)
+
+    def run(on):
+        monkeypatch.setattr(ops, "BWD_STATS", on)
+        for k in ops.NORM_BWD_STATS:
+            ops.NORM_BWD_STATS[k] = 0
+        t = [cl(x).to(DEV).requires_grad_(), w1.to(DEV).requires_grad_(), w2.to(DEV).requires_grad_(), gamma.to(DEV).requires_grad_(),
+             beta.to(DEV).requires_grad_()]
+        rm, rv = torch.zeros(Cm, device=DEV), torch.ones(Cm, device=DEV)
+        link = {}
+        y = ops.batch_norm(ops.conv3d(t[0], t[1]), t[3], t[4], rm, rv, relu_out=True, training=True, bwd_link=link)
+        out = ops.conv3d(y, t[2], None, (1, 1, 1), p2, bwd_stats=link)
+        out.backward(cl(go).to(DEV))
+        torch.cuda.synchronize()
+        return [t[0].grad, t[1].grad, t[2].grad, t[3].grad, t[4].grad], dict(ops.NORM_BWD_STATS)
+
+    g_on, n_on = run(True)
+    g_off, n_off = run(False)
+    assert n_on == {"epilogue": 1, "pass": 0} and n_off == {"epilogue": 0, "pass": 1}
+    refs = [ref[0].grad, ref[1].grad, ref[2].grad, ref[3].grad, ref[4].grad]
+    for i, (a, b, r) in enumerate(zip(g_on, g_off, refs)):
+        a = ncdhw(a) if i == 0 else a
+        b = ncdhw(b) if i == 0 else b
+        assert rel(a, r) < 2e-5, i
+        assert rel(a, b) < 2e-6, i
+
+
 def test_conv3d_sliced_io(ops):
     """input is a channel slice of a wider buffer and the output is written into a slice (in-place concat)."""
     B, D, Hh, W, Ci, Co = 2, 3, 6, 6, 16, 24
