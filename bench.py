@@ -267,6 +267,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    peak_mem = torch.cuda.max_memory_allocated()     # of the last timed step (the model resets the peak statistics at every forward)
     kt_steps = 0
     if timer:
         # EVERY rank runs this pass (its steps contain the gradient all-reduces: a rank-0-only pass would leave the collectives
@@ -310,7 +311,7 @@ def main():
                "config": {"workload": "mmvit4 CorrIFNet fwd+loss+bwd, %d bands/modality, %dx%d, batch %d per GPU, train mode "
                                       "(BASELINE configs[1])" % (args.bands, args.size, args.size, B),
                           "global_batch": world * B, "parallelism": "dp%d" % world, "loss": float(loss.item()),
-                          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2)}}
+                          "peak_mem_GB": round(peak_mem / 1e9, 2)}}
         # HBM bytes of the MFMA kernel family for ONE step of this workload, from the newest committed rocprofv3 PMC passes
         # (profiles/r??_mfma_traffic.json).  Quoted only while the kernel sources still are the ones the counters were taken with
         # (sha1 of csrc/ stored by tools/reduce_traffic.py); otherwise null - a stale number is worse than none.

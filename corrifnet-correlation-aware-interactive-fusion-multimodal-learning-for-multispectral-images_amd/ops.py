@@ -103,6 +103,20 @@ def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, add
     check(lib().corrif_gemm_fwd(g, stream()), "corrif_gemm_fwd")
 
 
+WGRAD_SPLITS_R1 = False      # diagnostics: the round-1 split rule ceil(2048 / tiles) (shorter fp32 accumulation chains, 1.6 waves of workgroups)
+
+
+def _old_wgrad_splits(R, M, N):
+    BM = 32 if M <= 32 else 64
+    BN = 256 if (M <= 16 and M % 4 == 0) else 128
+    if M >= 128 and N <= 64:
+        BM, BN = 128, 64
+    if BN == 256:
+        BM = 16
+    tiles = -(-M // BM) * -(-N // BN)
+    return int(max(1, min(-(-2048 // tiles), R // 256, 4096)))
+
+
 def wgrad(A, lda, Bm, ldb, Cs, Cout, ldc, R, M, N, geom, dev, Z=1, Zi=1, sA=(0, 0), sB=(0, 0), sC=(0, 0)):
     w = H.Wgrad()
     w.A, w.lda = A, lda
@@ -114,7 +128,7 @@ def wgrad(A, lda, Bm, ldb, Cs, Cout, ldc, R, M, N, geom, dev, Z=1, Zi=1, sA=(0, 
     w.sB_o, w.sB_i = sB
     w.sC_o, w.sC_i = sC
     w.g = geom
-    w.splits = 1 if Z > 1 else lib().corrif_wgrad_plan(R, M, N)
+    w.splits = 1 if Z > 1 else (_old_wgrad_splits(R, M, N) if WGRAD_SPLITS_R1 else lib().corrif_wgrad_plan(R, M, N))
     buf = None
     if w.splits > 1:
         buf = _ws(lib().corrif_wgrad_workspace(w), dev)

@@ -36,14 +36,16 @@ def oracle(case, dtype, sd):
     return out
 
 
-def hip(case, sd, serial, stream_k, tap=True, patch=True):
+def hip(case, sd, serial, stream_k, tap=True, patch=True, bwd_stats=True, splits_r1=False, stem=True, compact=True):
     ops.STREAM_K, ops.USE_PATCH, mmvit4.GRAD_TAP = stream_k, patch, tap
+    ops.BWD_STATS, ops.WGRAD_SPLITS_R1, ops.USE_STEM_KERNEL = bwd_stats, splits_r1, stem
     model = mmvit4.MMVit4()
     model.load_state_dict(sd)
     model = model.to(DEV).train()
     for m in model.modules():
         if isinstance(getattr(m, "p", None), float):
             m.p = 0.0
+    model.decoder_fuse.compact_skips = compact
     if serial:
         model.concurrent_branches, model.decoder_split, model.decoder_fuse.concurrent_skips = False, 0, False
     x, mask = helpers.make_inputs(case["B"], case["D"], case["H"], case["W"])
@@ -66,12 +68,14 @@ def main():
     r64 = oracle(case, torch.float64, sd)
     r32 = oracle(case, torch.float32, sd)
     print("oracle fp32 vs fp64: pred gap %.3e" % (r32["__pred__"] - r64["__pred__"]).abs().max().item(), flush=True)
-    variants = [("serial, one workgroup per tile", dict(serial=True, stream_k=False)),
-                ("serial, stream-K", dict(serial=True, stream_k=True)),
-                ("concurrent, one workgroup per tile", dict(serial=False, stream_k=False)),
-                ("concurrent, stream-K", dict(serial=False, stream_k=True)),
+    variants = [("default", dict(serial=False, stream_k=False)),
+                ("BatchNorm backward reductions as their own pass", dict(serial=False, stream_k=False, bwd_stats=False)),
+                ("round-1 weight-gradient splits", dict(serial=False, stream_k=False, splits_r1=True)),
+                ("both of the above", dict(serial=False, stream_k=False, bwd_stats=False, splits_r1=True)),
+                ("scalar-gather stem", dict(serial=False, stream_k=False, stem=False)),
+                ("materialised skip branch", dict(serial=False, stream_k=False, compact=False)),
                 ("serial, no grad_tap", dict(serial=True, stream_k=False, tap=False)),
-                ("serial, no patch kernels", dict(serial=True, stream_k=False, patch=False))]
+                ("stream-K", dict(serial=False, stream_k=True))]
     base = None
     for name, kw in variants:
         h = hip(case, sd, **kw)
