@@ -126,8 +126,10 @@ __device__ __forceinline__ void store_cols(float* __restrict__ p, int lane, cons
 
 // =============================================================================================== forward
 // grid (N / 128, B * heads); wave w owns queries q0 + 32 w ..; the workgroup streams 64-key K / V tiles through LDS.
+// (the dropout variant would need one spilled register to fit three waves per SIMD: scratch memory has to be set up on the queue
+// at the first launch, which showed up as a 18 ms outlier - two waves, no scratch)
 template <bool DROP>
-__global__ __launch_bounds__(256, 3) void flash_fwd_kernel(FlashArgs p) {
+__global__ __launch_bounds__(256, DROP ? 2 : 3) void flash_fwd_kernel(FlashArgs p) {
     __shared__ __attribute__((aligned(16))) float Ks[KT * TP];
     __shared__ __attribute__((aligned(16))) float Vs[KT * TP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

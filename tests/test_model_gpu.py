@@ -368,31 +368,6 @@ def test_large_baseline_configs_fwd_bwd(name, force_single_stream, monkeypatch):
             assert e_hip < max(10 * e_fix, 1e-3), (k, e_hip, e_fix)
 
 
-def test_headline_batch_against_the_oracle_on_the_device():
-    """BASELINE configs[1] itself - batch 32, 4 bands, 224^2, forward + loss + backward - against the oracle's modules evaluated on the
-    device in fp32 (stock ATen / MIOpen kernels; its fp64 run does not fit next to ours).  Both sides are fp32 realisations of an
-    arithmetic whose own fp32-vs-fp64 gap is 2-3e-4 on the sigmoid output at this size, so the bar is that gap, not a kernel tolerance:
-    it catches what only shows at the headline batch (32-sample BatchNorm statistics, the (i, b) = divmod(3b'+i', 32) re-view of the
-    inter-modal correlation, 32-bit index ranges of the 128^3 decoder tensors), while the tight parity evidence stays with the
-    reference fixtures at batch 1-4."""
-    import mmvit4
-    case = dict(B=32, D=4, H=224, W=224, mode="train_nodrop", conv_gain=1.0, wseed=21)
-    model, pred, mask, loss, sd = run_hip(case)
-    ps = pred.detach()[:, :, 0, ::4, ::4].double().cpu().numpy()
-    n = 32 * 224 * 224
-    jac = float(mmvit4.Jaccard2(mask[:, 0].reshape(n, 1).to(DEV), pred.detach()[:, 0].reshape(n, 1)).cpu()[0])
-    hip_loss = loss.item()
-    grads = {k: p.grad.double().cpu() for k, p in model.named_parameters() if k in helpers.GRAD_KEYS}
-    assert sum(1 for p in model.parameters() if p.grad is None) == 18
-    del model, pred, loss
-    torch.cuda.empty_cache()
-    r32 = _oracle_on_device(case, torch.float32, sd)
-    assert np.abs(ps - r32["pred_sample"]).max() < 2e-3, np.abs(ps - r32["pred_sample"]).max()
-    assert abs(hip_loss - r32["loss"]) < 2e-4 and abs(jac - r32["jaccard2"]) < 2e-4
-    errs = sorted(((grads[k] - r32["grads"][k].cpu()).norm() / r32["grads"][k].cpu().norm().clamp_min(1e-30)).item() for k in helpers.GRAD_KEYS)
-    assert errs[len(errs) // 2] < 2e-2 and errs[-1] < 0.7, (errs[len(errs) // 2], errs[-1])      # median of 45 tensors; the worst are the analytically cancelling sums
-
-
 def test_module_surface():
     """the calls F2_MAIN / F4_TRAIN make on the model."""
     import mmvit4
