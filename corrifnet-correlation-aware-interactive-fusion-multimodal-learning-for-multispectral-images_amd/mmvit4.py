@@ -18,6 +18,12 @@ import torch.nn as nn
 
 import ops
 
+# The decoder / multimodal-transformer parameters are used by two sample-group lanes on two streams (MMVit4.decoder_split), so the second
+# lane's gradient reaches an AccumulateGrad node that lives on the first lane's stream: autograd inserts the stream wait the accumulation
+# needs and warns that the streams differ.  The mismatch is intentional here.
+if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
 basic_dims = 8
 transformer_basic_dims = 512
 mlp_dim = 512
