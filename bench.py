@@ -267,7 +267,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    peak_mem = torch.cuda.max_memory_allocated()     # of the last timed step (the model resets the peak statistics at every forward)
+    peak_mem = torch.cuda.max_memory_allocated()     # since the model's last memory-plan measurement (its first steps reset the peak statistics)
     kt_steps = 0
     if timer:
         # EVERY rank runs this pass (its steps contain the gradient all-reduces: a rank-0-only pass would leave the collectives

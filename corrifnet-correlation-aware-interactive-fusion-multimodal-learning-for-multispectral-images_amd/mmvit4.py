@@ -595,24 +595,25 @@ class MMVit4(nn.Module):
 
     def _wants_single_stream(self, x):
         """Memory plan per input shape.  The first training step at a shape is scheduled from an a-priori estimate of its autograd state
-        (`_memory_limited`); every later step from the MEASURED peak of the step before it (torch.cuda.max_memory_allocated, reset at
-        each forward): multi-stream while the peak stays under 55 % of the device memory, single-stream above 75 %, no change in
-        between (the multi-stream schedule itself needs more than the single-stream one: per-stream pools)."""
+        (`_memory_limited`); the next three steps from the MEASURED peak of the step before (torch.cuda.max_memory_allocated, reset at
+        those forwards): multi-stream while the peak stays under 55 % of the device memory, single-stream above 75 %, no change in
+        between (the multi-stream schedule itself needs more than the single-stream one: per-stream pools).  After that the plan of the
+        shape is final and the process-wide peak statistics are not touched any more."""
         key, dev = tuple(x.shape), x.device
         total = torch.cuda.get_device_properties(dev).total_memory
         plan = self._mem_plan.get(key)
         if plan is None:
-            single = _memory_limited(x)
-        else:
+            plan = self._mem_plan[key] = [_memory_limited(x), 0]         # [single-stream?, measured steps]
+        elif plan[1] < 3:
             peak = torch.cuda.max_memory_allocated(dev)
-            single = plan
             if peak > 0.75 * total:
-                single = True
+                plan[0] = True
             elif peak < 0.55 * total:
-                single = False
-        self._mem_plan[key] = single
-        torch.cuda.reset_peak_memory_stats(dev)
-        return single
+                plan[0] = False
+            plan[1] += 1
+        if plan[1] < 3:                       # measuring: afterwards the decision is final and the caller's peak statistics are left alone
+            torch.cuda.reset_peak_memory_stats(dev)
+        return plan[0]
 
     def _forward(self, x):
         B = x.shape[0]
