@@ -225,6 +225,8 @@ def main():
         ops.STREAM_K = os.environ["CORRIF_STREAM_K"] == "1"
     if os.environ.get("CORRIF_STREAM_K_LONG") is not None:   # A/B switch: 0 = no stream-K split for the long-K, few-tile GEMMs either
         ops.STREAM_K_LONG = os.environ["CORRIF_STREAM_K_LONG"] == "1"
+    if os.environ.get("CORRIF_INTERLEAVE") is not None:      # A/B switch: 0 = the host enqueues one modality branch after the other
+        model.interleave_branches = os.environ["CORRIF_INTERLEAVE"] == "1"
     if os.environ.get("CORRIF_BWD_STATS") is not None:       # A/B switch: 0 = every BatchNorm backward runs its own reduction pass
         ops.BWD_STATS = os.environ["CORRIF_BWD_STATS"] == "1"
     if os.environ.get("CORRIF_SIDE_WGRAD") is not None:      # A/B switch: 0 = the encoders' weight gradients stay on their branch stream

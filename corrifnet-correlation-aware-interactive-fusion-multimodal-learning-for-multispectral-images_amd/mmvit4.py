@@ -275,7 +275,18 @@ class Encoder(nn.Module):
 
     def forward(self, x, m, cats):
         """x: [B, D, H, W] view of modality m; cats[l]: concat buffer of level l (None until the first modality allocates it)."""
+        g = self.steps(x, m, cats)
+        try:
+            while True:
+                next(g)
+        except StopIteration as done:
+            return done.value
+
+    def steps(self, x, m, cats):
+        """`forward` as a generator that yields after the stem, after every ResNet layer and before the adapt / conv6 tail, so that
+        MMVit4 can enqueue the three modality branches layer by layer in turn (see MMVit4._forward); returns forward's value."""
         f = ops.maxpool133(self.e1_bn(self.e1_c1(x), relu_in=True))          # conv -> ReLU -> BN -> pool (mmvit4.py:172-174)
+        yield
         feats, links = [f], []
         tap = GRAD_TAP and torch.is_grad_enabled()
         for layer in (self.e2, self.e3, self.e4, self.e5):
@@ -285,6 +296,7 @@ class Encoder(nn.Module):
             links.append(link)
             f = layer(f, link)
             feats.append(f)
+            yield
         links.append(None)
         outs = []
         B = x.shape[0]
@@ -538,6 +550,7 @@ class MMVit4(nn.Module):
         # inter-modal correlation: run them on three HIP streams so that their small late-stage launches (e4/e5: 1-2
         # workgroups per CU each) fill the 256 CUs together.  Same kernels, same order per branch: results are unchanged.
         self.concurrent_branches = True
+        self.interleave_branches = True      # enqueue the three branches layer by layer in turn (diagnostics / A-B: False = branch after branch)
         self._streams = None
         # The decoder has no cross-sample coupling (InstanceNorm is per sample, no BatchNorm): run it as two half-batch chains on
         # two streams so that the HBM-bound stages of one half (norm statistics / apply, resampling) overlap the MFMA-bound stages
@@ -625,10 +638,16 @@ class MMVit4(nn.Module):
         cats.append(torch.empty((B, P3, P3, P3, num_modals * basic_dims * 8), dtype=torch.float32, device=x.device))
         feats, skip, qkv = [None] * 3, [None] * 3, [None] * 3
 
-        def branch(i, m):
-            feats[i] = getattr(self, m + "_encoder")(x[:, i], i, cats)
+        def branch(i, m, interleaved):
+            """one modality branch as a generator (yields between the encoder's layers and before the transformer)"""
+            enc = getattr(self, m + "_encoder")
+            if interleaved:
+                feats[i] = yield from enc.steps(x[:, i], i, cats)
+            else:
+                feats[i] = enc(x[:, i], i, cats)
             tok = getattr(self, m + "_encode_conv")(feats[i][5]).view(B, P3 ** 3, T)       # channels-last == token layout (:458-461)
             skip[i] = tok
+            yield
             tr = getattr(self, m + "_transformer")(tok, getattr(self, m + "_pos"))
             qkv[i] = getattr(self, "qkv_" + m)(tr.view(B, P3, P3, P3, T)).view(B, P3 ** 3, 3 * T)
 
@@ -644,8 +663,20 @@ class MMVit4(nn.Module):
                 _rs(x, st)
                 for c in cats:
                     _rs(c, st)
-                with torch.cuda.stream(st):
-                    branch(i, m)
+            # The host enqueues the three branches LAYER BY LAYER in turn.  Branch after branch, the first stream ran alone while the
+            # host was still enqueuing it (and, because autograd replays nodes in reverse creation order, the last stream ran alone at
+            # the end of the backward while its 1/3 of the nodes were the only ones left): with interleaved creation order all three
+            # streams are fed from the first to the last millisecond of both passes.  Per branch the kernels and their order are the
+            # same, so results are unchanged.
+            gens = [branch(i, m, self.interleave_branches) for i, m in enumerate(_MODS)]
+            alive = list(range(num_modals))
+            while alive:
+                for i in list(alive):
+                    with torch.cuda.stream(self._streams[i]):
+                        try:
+                            next(gens[i])
+                        except StopIteration:
+                            alive.remove(i)
             for st in self._streams:
                 self._edges.edge(st, cur)
             for i in range(num_modals):        # branch outputs are consumed on the caller's stream from here on
@@ -653,7 +684,8 @@ class MMVit4(nn.Module):
                     _rs(t, cur)
         else:
             for i, m in enumerate(_MODS):
-                branch(i, m)
+                for _ in branch(i, m, False):
+                    pass
         fused = [getattr(self, "fusion%d" % (l + 1))(ops.cat_channels(cats[l], *[feats[i][l] for i in range(num_modals)]))
                  for l in range(6)]            # fused[4] (fusion5) is computed and never consumed, as in the reference (:453)
         corr = ops.inter_corr(qkv[0], qkv[1], qkv[2])                                      # mmvit4.py:481-503
