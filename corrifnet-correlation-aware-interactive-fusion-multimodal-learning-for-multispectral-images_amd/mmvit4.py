@@ -58,9 +58,19 @@ class _Edges:
 
     def __init__(self):
         self.events, self.i = [], 0
+        self._eager, self._captured = self.events, []
 
     def reset(self):
+        """rewind at the start of a forward.  A forward that is being captured into a HIP graph gets a FRESH set of events, kept alive
+        with the module and never recorded again: an event that already sits in one instantiated graph must not be re-recorded into
+        another capture (a second GraphedForward on the same model - another batch size - crashed the HIP runtime that way), nor mixed
+        with the eager pool."""
         self.i = 0
+        if torch.cuda.is_current_stream_capturing():
+            self.events = []
+            self._captured.append(self.events)
+        else:
+            self.events = self._eager
 
     def mark(self, src):
         """a pooled event recorded on `src` now (wait for it later with stream.wait_event)"""

@@ -238,6 +238,18 @@ def test_hip_graph_eval_forward_is_bit_identical_to_eager():
     assert hip.concurrent_branches and hip.decoder_split == 2 and hip.decoder_fuse.concurrent_skips
     assert torch.equal(g1(x1), e1)
     assert torch.equal(g(x2), e2)                         # the first graph is still replayable
+    # a second MULTI-stream capture on the same model at another batch size (two sample-group lanes instead of one), with both
+    # graphs alive: every captured forward records its own set of fork/join events (tools/graph_eval.py crashed here in round 2
+    # while the events of the first graph were re-recorded into the second capture)
+    x4, _ = helpers.make_inputs(4, 3, 64, 64, seed=3)
+    x4 = x4.to(DEV)
+    with torch.no_grad():
+        e4 = hip(x4).clone()
+    g4 = train.GraphedForward(hip, x4)
+    assert torch.equal(g4(x4), e4)
+    assert torch.equal(g(x1), e1) and torch.equal(g1(x2), e2)
+    with torch.no_grad():
+        assert torch.equal(hip(x4), e4)
     torch.cuda.synchronize()
 
 
