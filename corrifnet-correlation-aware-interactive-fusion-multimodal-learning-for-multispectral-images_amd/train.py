@@ -171,8 +171,9 @@ def evaluate(model, loader, device):
 class GraphedForward:
     """Eval-mode forward captured ONCE per input shape in a HIP graph and replayed (the per-image metric loop runs at batch 1,
     where the ~2000 launches of a forward cost more host time than the GPU needs: a step is launch-bound, not MFMA-bound).
-    The capture takes the module's real schedule - the three modality-branch streams, the sample-group lanes and the decoder's
-    skip stream fork from the capturing stream and re-join it - so the replay keeps their concurrency (1.9x faster than eager at
+    The capture takes the module's real schedule - the three modality-branch streams and the decoder's skip stream fork from the
+    capturing stream and re-join it (the sample-group lanes are left out of a capture: mmvit4._run_lanes) - so the replay keeps their
+    concurrency (1.9x faster than eager at
     batch 1 in round 1, 1.24x for a single-stream capture).  Round 1 had to capture single-stream because the process crashed after
     a multi-stream capture; the cause was events destroyed while their stream was still capturing (mmvit4._Edges explains it) and
     is fixed by the model's persistent fork/join events.  `single_stream=True` still forces the one-stream schedule.
