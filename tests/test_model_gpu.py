@@ -271,9 +271,12 @@ def _oracle_on_device(case, dtype, sd, device=DEV):
     O.set_dropout(ref, False)
     x, mask = helpers.make_inputs(case["B"], case["D"], case["H"], case["W"])
     x, mask = x.to(device=device, dtype=dtype), mask.to(device=device, dtype=dtype)
-    pred = ref(x)
-    loss = O.train_step_loss(pred, mask)
-    loss.backward()
+    # MIOpen off: its per-geometry kernel search / compilation costs minutes per case in fp32 on a fresh box (fp64 never goes through
+    # it); ATen's own convolution kernels are slower per call and need no warm-up
+    with torch.backends.cudnn.flags(enabled=False):
+        pred = ref(x)
+        loss = O.train_step_loss(pred, mask)
+        loss.backward()
     torch.cuda.synchronize()
     out = {"pred_sample": pred.detach()[:, :, 0, ::4, ::4].double().cpu().numpy(), "loss": loss.item(),
            "grads": {k: p.grad.double() for k, p in ref.named_parameters() if k in helpers.GRAD_KEYS},
@@ -309,8 +312,9 @@ def test_large_baseline_configs_fwd_bwd(name, force_single_stream, monkeypatch):
     """BASELINE configs[0] (batch 4, 4 bands, 224^2: the one configuration the reference itself runs, F4_TRAIN.py:52-61; fixture =
     the upstream reference's own fp32 run), configs[2] (8 bands, 256^2) and configs[4] (12 bands, 512^2) geometry, forward AND
     backward, at batch >= 2 (so the inter-modal re-view and the BatchNorm batch statistics are non-trivial).  Truth = the oracle's modules evaluated on the device in
-    fp64 (pinned by the test above), bracket = the same in fp32 (the reference's arithmetic); the 8-band case is additionally checked
-    against a fixture the CPU oracle produced in fp32 on the GPU box's host (tests/golden/make_golden_large.py, 12 min of host time).
+    fp64 (pinned by the test above); the fp32 side of the bracket (the reference's arithmetic) is the committed fixture where one exists
+    - the upstream reference's own run for configs[0], the CPU oracle's run on the GPU box's host for the 8-band case
+    (tests/golden/make_golden_large.py, 12 min of host time) - and the same modules on the device in fp32 for the 12-band case.
     The 8-band case runs through the single-stream schedule `MMVit4.forward` falls back to near the HBM capacity (what configs[2] at
     B = 64 and configs[4] at B = 16 actually execute), forced here by patching the memory estimate.  Brackets as for the reference
     fixtures: 3x the fp32 arithmetic's own error against fp64 for the prediction, 10x (floor 1e-3) for the sampled gradients."""
@@ -334,10 +338,35 @@ def test_large_baseline_configs_fwd_bwd(name, force_single_stream, monkeypatch):
     assert sum(1 for p in model.parameters() if p.grad is None) == 18
     del model, pred, loss
     torch.cuda.empty_cache()
+    r64 = _oracle_on_device(case, torch.float64, sd)
+    path = os.path.join(helpers.GOLDEN, name + ".npz")
+    if os.path.exists(path):
+        # fp32 side of the bracket = the committed fixture: the upstream reference's own fp32 run (configs[0]) / the CPU oracle's fp32 run on
+        # the GPU box's host (8 bands).  (Evaluating the oracle on the device in fp32 as well costs minutes of MIOpen kernel search per
+        # geometry and adds nothing the fixture does not already pin.)
+        g = np.load(path)
+        gap = np.abs(g["f32/pred_sample"] - r64["pred_sample"]).max()
+        assert gap < 2e-3, gap                                   # the fixture and the device truth describe the same run
+        assert np.abs(ps - r64["pred_sample"]).max() < max(3 * gap, 5e-5), (np.abs(ps - r64["pred_sample"]).max(), gap)
+        assert abs(float(jac[0]) - r64["jaccard2"]) < 1e-5
+        assert abs(hip_loss - r64["loss"]) < max(1e-5, 3 * abs(float(g["f32/loss"]) - r64["loss"]))
+        assert np.abs(ps - g["f32/pred_sample"]).max() < max(4 * gap, 5e-5)
+        bad = []
+        for k in helpers.GRAD_KEYS:              # sampled gradients: HIP and the fixture against the fp64 truth
+            t = sample(r64["grads"][k])
+            scale = max(np.abs(t).max(), 1e-30)
+            e_fix = np.abs(g["f32/grad_sample/" + k] - t).max() / scale
+            e_hip = np.abs(sample(grads[k]) - t).max() / scale
+            if e_hip > max(10 * e_fix, 1e-3):
+                bad.append((k, e_hip, e_fix))
+        assert not bad, bad
+        for k, b in bufs.items():
+            t = r64["bufs"][k]
+            assert ((b - t).norm() / t.norm()).item() < 1e-4, k
+        return
     r32 = _oracle_on_device(case, torch.float32, sd)
     r32g = {k: v.cpu() for k, v in r32["grads"].items()}
     r32["grads"] = None
-    r64 = _oracle_on_device(case, torch.float64, sd)
     gap = np.abs(r32["pred_sample"] - r64["pred_sample"]).max()
     assert np.abs(ps - r64["pred_sample"]).max() < max(3 * gap, 5e-5), (np.abs(ps - r64["pred_sample"]).max(), gap)
     assert abs(float(jac[0]) - r64["jaccard2"]) < 1e-5
@@ -354,18 +383,6 @@ def test_large_baseline_configs_fwd_bwd(name, force_single_stream, monkeypatch):
     for k, b in bufs.items():
         t = r64["bufs"][k]
         assert ((b - t).norm() / t.norm()).item() < max(3 * ((r32["bufs"][k] - t).norm() / t.norm()).item(), 1e-4), k
-    path = os.path.join(helpers.GOLDEN, name + ".npz")
-    if os.path.exists(path):                     # the fp32 run of the same case by the upstream reference (configs[0]) / by the CPU oracle on the
-        g = np.load(path)                        # GPU box's host cores (8 bands): the device fp32 evaluation must reproduce it, HIP must bracket it
-        assert np.abs(r32["pred_sample"] - g["f32/pred_sample"]).max() < max(gap, 2e-5)
-        assert np.abs(ps - g["f32/pred_sample"]).max() < max(4 * gap, 5e-5)
-        assert abs(hip_loss - float(g["f32/loss"])) < max(1e-5, 4 * abs(r32["loss"] - r64["loss"]))
-        for k in helpers.GRAD_KEYS:              # sampled gradients of the fixture against the fp64 truth: same bracket
-            t = sample(r64["grads"][k])
-            scale = max(np.abs(t).max(), 1e-30)
-            e_fix = np.abs(g["f32/grad_sample/" + k] - t).max() / scale
-            e_hip = np.abs(sample(grads[k]) - t).max() / scale
-            assert e_hip < max(10 * e_fix, 1e-3), (k, e_hip, e_fix)
 
 
 def test_module_surface():

@@ -26,8 +26,9 @@ def oracle(case, dtype, sd):
     O.set_dropout(ref, False)
     x, mask = helpers.make_inputs(case["B"], case["D"], case["H"], case["W"])
     x, mask = x.to(device=DEV, dtype=dtype), mask.to(device=DEV, dtype=dtype)
-    pred = ref(x)
-    O.train_step_loss(pred, mask).backward()
+    with torch.backends.cudnn.flags(enabled=False):      # no MIOpen kernel search (minutes per geometry in fp32 on a fresh box)
+        pred = ref(x)
+        O.train_step_loss(pred, mask).backward()
     torch.cuda.synchronize()
     out = {k: p.grad.double().cpu() for k, p in ref.named_parameters() if p.grad is not None}
     out["__pred__"] = pred.detach().double().cpu()
