@@ -35,7 +35,8 @@ class Gemm(C.Structure):
                 ("oo_d", i32), ("oo_h", i32), ("oo_w", i32),
                 ("stats_part", ptr), ("stats_rows_per_group", i64), ("stats_relu", i32), ("ws", ptr), ("no_split", i32),
                 ("addend2", ptr), ("ld_add2", i64),
-                ("bstats_x", ptr), ("bstats_ldx", i64), ("bstats_y", ptr), ("bstats_ldy", i64), ("bstats_mean", ptr), ("bstats_rstd", ptr)]
+                ("bstats_x", ptr), ("bstats_ldx", i64), ("bstats_y", ptr), ("bstats_ldy", i64), ("bstats_mean", ptr), ("bstats_rstd", ptr),
+                ("zs_bias", i64), ("zs_add", i64), ("zs_add2", i64), ("zs_stats", i64), ("zs_bsx", i64), ("zs_bsy", i64), ("zs_bsstat", i64)]
 
 
 class Wgrad(C.Structure):
@@ -63,7 +64,7 @@ _SIGS = {
     "corrif_gemm_fwd_workspace": (C.c_size_t, [C.POINTER(Gemm)]),
     "corrif_wgrad": (i32, [C.POINTER(Wgrad), ptr]),
     "corrif_wgrad_workspace": (C.c_size_t, [C.POINTER(Wgrad)]),
-    "corrif_wgrad_plan": (i32, [i32, i32, i32]),
+    "corrif_wgrad_plan": (i32, [i32, i32, i32, i32]),
     "corrif_conv3_patch": (i32, [C.POINTER(Conv3Patch), ptr]),
     "corrif_conv3_patch_cc": (i32, [i32, i32]),
     "corrif_conv3_patch_wgrad": (i32, [C.POINTER(Conv3PatchWgrad), ptr]),
@@ -88,6 +89,13 @@ _SIGS = {
     "corrif_norm_bwd": (i32, [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, ptr, i64, i32, i32, i32, i32, ptr, ptr]),
     "corrif_norm_bwd_pre": (i32, [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, ptr, i64, i32, i32, ptr, i32, ptr, ptr]),
     "corrif_norm_workspace": (C.c_size_t, [i64, i32, i32]),
+    "corrif_norm_stats_g": (i32, [ptr, i64, i64, i32, i32, i32, f32, ptr, ptr, ptr, ptr, f32, ptr, ptr]),
+    "corrif_norm_stats_finalize_g": (i32, [ptr, i32, i32, i32, i64, f32, ptr, ptr, ptr, ptr, f32, ptr]),
+    "corrif_norm_apply_g": (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, i64, i64, i32, i32, i32, i64, ptr]),
+    "corrif_norm_bwd_g": (i32, [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, ptr, i64, i32, i32, i32, i32, i64, ptr, ptr]),
+    "corrif_norm_bwd_pre_g": (i32, [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, ptr, i64, i32, i32, i32, i64, ptr, i32, ptr, ptr]),
+    "corrif_col_sum_g": (i32, [ptr, i64, i64, i32, i32, ptr, ptr, ptr]),
+    "corrif_stack_groups": (i32, [ptr, i32, ptr, i64, ptr]),
     "corrif_layernorm_fwd": (i32, [ptr, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, f32, ptr]),
     "corrif_layernorm_bwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr]),
     "corrif_layernorm_workspace": (C.c_size_t, [i64, i32]),
@@ -150,7 +158,7 @@ def lib():
             fn = getattr(l, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if l.corrif_abi_version() != 5:
+        if l.corrif_abi_version() != 6:
             raise RuntimeError("corrif: ABI version mismatch")
         _lib = l
     return _lib

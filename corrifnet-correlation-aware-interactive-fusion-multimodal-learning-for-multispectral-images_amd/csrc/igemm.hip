@@ -227,7 +227,14 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, const float* __
 // 128*TN-byte contiguous row segments.  (The caller has fenced the A/B tiles with a __syncthreads() before calling.)
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restrict__ C, float* lds, const int m0, const int n0,
-                                              f32x16 (&acc)[BM / WM / 32][BN / WN / 32]) {
+                                              f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const int zo) {
+    // per-group epilogue operands of a grouped launch (zo = outer batch index; all strides are 0 for an ordinary launch)
+    const float* __restrict__ const bias = p.bias ? p.bias + zo * p.zs_bias : nullptr;
+    const float* __restrict__ const addend = p.addend ? p.addend + zo * p.zs_add : nullptr;
+    const float* __restrict__ const addend2 = p.addend2 ? p.addend2 + zo * p.zs_add2 : nullptr;
+    const float* __restrict__ const bs_x = p.bs_x ? p.bs_x + zo * p.zs_bsx : nullptr;
+    const float* __restrict__ const bs_y = p.bs_y ? p.bs_y + zo * p.zs_bsy : nullptr;
+    double* __restrict__ const stats_part = p.stats_part ? p.stats_part + zo * p.zs_stats : nullptr;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int SP = GemmCfg<BM, BN, WM, WN>::SP;
     constexpr int CQ = TN * 8;                    // float4 chunks per staged row
@@ -237,20 +244,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
     float* const stg = lds + wave * 32 * SP;
     const int rr = lane / CQ, cq = lane % CQ;
     const int col = n0 + wn * TN * 32 + cq * 4;   // this lane's 4 output columns (fixed for all passes)
-    const bool vec_ok = !(p.ldc & 3) && !((uintptr_t)C & 15) && (!p.addend || (!(p.ld_add & 3) && !((uintptr_t)p.addend & 15))) &&
-                        (!p.addend2 || (!(p.ld_add2 & 3) && !((uintptr_t)p.addend2 & 15)));
+    const bool vec_ok = !(p.ldc & 3) && !((uintptr_t)C & 15) && (!addend || (!(p.ld_add & 3) && !((uintptr_t)addend & 15))) &&
+                        (!addend2 || (!(p.ld_add2 & 3) && !((uintptr_t)addend2 & 15)));
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
+    if (bias) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (col + e < p.N) bv[e] = p.bias[col + e];
+            if (col + e < p.N) bv[e] = bias[col + e];
     }
     double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};      // fused norm statistics of this lane's 4 columns (double: no cancellation loss)
     f32x4 bmu = {0.f, 0.f, 0.f, 0.f}, brs = {0.f, 0.f, 0.f, 0.f};      // backward-statistics mode: mean / rstd of this lane's 4 columns
-    if (p.bs_x) {
+    if (bs_x) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (col + e < p.N) { bmu[e] = p.bs_mean[col + e]; brs[e] = p.bs_rstd[col + e]; }
+            if (col + e < p.N) { bmu[e] = p.bs_mean[zo * p.zs_bsstat + col + e]; brs[e] = p.bs_rstd[zo * p.zs_bsstat + col + e]; }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -267,7 +274,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
             f32x4 v = *reinterpret_cast<const f32x4*>(&stg[lr * SP + cq * 4]);
             if (row >= p.M || col >= p.N) continue;
             v += bv;
-            if (p.stats_part && !p.bs_x) {
+            if (stats_part && !bs_x) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const double sv = (double)(p.stats_relu ? fmaxf(v[e], 0.f) : v[e]);
@@ -285,8 +292,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
             }
             float* __restrict__ dst = C + orow * p.ldc + col;
             if (vec_ok && col + 3 < p.N) {
-                if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + (int64_t)row * p.ld_add + col);
-                if (p.addend2) v += *reinterpret_cast<const f32x4*>(p.addend2 + (int64_t)row * p.ld_add2 + col);
+                if (addend) v += *reinterpret_cast<const f32x4*>(addend + (int64_t)row * p.ld_add + col);
+                if (addend2) v += *reinterpret_cast<const f32x4*>(addend2 + (int64_t)row * p.ld_add2 + col);
                 if (p.act == CORRIF_ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -294,10 +301,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
                 }
-                if (p.bs_x) {      // v is the complete gradient w.r.t. the producing BatchNorm's output (addends included)
-                    const f32x4 xv = *reinterpret_cast<const f32x4*>(p.bs_x + (int64_t)row * p.bs_ldx + col);
+                if (bs_x) {      // v is the complete gradient w.r.t. the producing BatchNorm's output (addends included)
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(bs_x + (int64_t)row * p.bs_ldx + col);
                     f32x4 yv = {1.f, 1.f, 1.f, 1.f};
-                    if (p.bs_y) yv = *reinterpret_cast<const f32x4*>(p.bs_y + (int64_t)row * p.bs_ldy + col);
+                    if (bs_y) yv = *reinterpret_cast<const f32x4*>(bs_y + (int64_t)row * p.bs_ldy + col);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float gm = yv[e] > 0.f ? v[e] : 0.f;
@@ -312,22 +319,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
                 for (int e = 0; e < 4; ++e) {
                     if (col + e >= p.N) break;
                     float x = v[e];
-                    if (p.addend) x += p.addend[(int64_t)row * p.ld_add + col + e];
-                    if (p.addend2) x += p.addend2[(int64_t)row * p.ld_add2 + col + e];
+                    if (addend) x += addend[(int64_t)row * p.ld_add + col + e];
+                    if (addend2) x += addend2[(int64_t)row * p.ld_add2 + col + e];
                     if (p.act == CORRIF_ACT_RELU) x = fmaxf(x, 0.f);
                     else if (p.act == CORRIF_ACT_GELU) x = gelu_erf(x);
-                    if (p.bs_x) {
-                        const float yv = p.bs_y ? p.bs_y[(int64_t)row * p.bs_ldy + col + e] : 1.f;
+                    if (bs_x) {
+                        const float yv = bs_y ? bs_y[(int64_t)row * p.bs_ldy + col + e] : 1.f;
                         const float gm = yv > 0.f ? x : 0.f;
                         ssum[e] += (double)gm;
-                        ssq[e] += (double)gm * (double)((p.bs_x[(int64_t)row * p.bs_ldx + col + e] - bmu[e]) * brs[e]);
+                        ssq[e] += (double)gm * (double)((bs_x[(int64_t)row * p.bs_ldx + col + e] - bmu[e]) * brs[e]);
                     }
                     dst[e] = x;
                 }
             }
         }
     }
-    if (p.stats_part) {       // TM == 2: the wave's rows are one 64-row block; sum over the RPP lanes that share a column chunk
+    if (stats_part) {       // TM == 2: the wave's rows are one 64-row block; sum over the RPP lanes that share a column chunk
 #pragma unroll
         for (int off = CQ; off < 64; off <<= 1)
 #pragma unroll
@@ -338,7 +345,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (col + e < p.N) {
-                    double* o = p.stats_part + (((int64_t)g * p.N + col + e) * p.stats_chunks + chunk) * 2;
+                    double* o = stats_part + (((int64_t)g * p.N + col + e) * p.stats_chunks + chunk) * 2;
                     o[0] = ssum[e];
                     o[1] = ssq[e];
                 }
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     gemm_mainloop<BM, BN, WM, WN, VEC, GEMM, BL>(p, A, B, lds, m0, n0, 0, (p.K + BK - 1) / BK, acc);
-    gemm_epilogue<BM, BN, WM, WN>(p, C, lds, m0, n0, acc);
+    gemm_epilogue<BM, BN, WM, WN>(p, C, lds, m0, n0, acc, zo);
 }
 
 // unit boundary of stream-K workgroup g: floor(g * U / G)
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(GemmArgs p) {
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         gemm_mainloop<BM, BN, WM, WN, VEC, GEMM, BL>(p, A, B, lds, m0, n0, k0, k1, acc);
         if (k0 == 0 && k1 == nk) {
-            gemm_epilogue<BM, BN, WM, WN>(p, p.C + zo * p.sC_o + zi * p.sC_i, lds, m0, n0, acc);
+            gemm_epilogue<BM, BN, WM, WN>(p, p.C + zo * p.sC_o + zi * p.sC_i, lds, m0, n0, acc, zo);
             __syncthreads();                                  // the staging area is the next piece's A/B tile
         } else {
             // partial piece: raw accumulators to this workgroup's slab (0: the piece its range starts with, 1: a later one)
@@ -469,7 +476,7 @@ __global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(GemmArgs p) {
     const int z = t / p.sk_tiles_mn, tile = t - z * p.sk_tiles_mn;
     const int zo = z / p.Zi, zi = z - zo * p.Zi;
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-    gemm_epilogue<BM, BN, WM, WN>(p, p.C + zo * p.sC_o + zi * p.sC_i, lds, m0, n0, acc);
+    gemm_epilogue<BM, BN, WM, WN>(p, p.C + zo * p.sC_o + zi * p.sC_i, lds, m0, n0, acc, zo);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
@@ -580,8 +587,11 @@ static int gemm_fwd_impl(const CorrifGemm* p, void* stream, bool plan_only, size
         if (!p->stats_part || !p->bstats_mean || !p->bstats_rstd || p->bstats_ldx < p->N || (p->bstats_y && p->bstats_ldy < p->N)) return CORRIF_EINVAL;
         if ((p->bstats_ldx & 3) || (p->bstats_ldy & 3) || ((uintptr_t)p->bstats_x & 15) || ((uintptr_t)p->bstats_y & 15)) return CORRIF_EUNSUPPORTED;
     }
+    a.zs_bias = p->zs_bias; a.zs_add = p->zs_add; a.zs_add2 = p->zs_add2; a.zs_stats = p->zs_stats; a.zs_bsx = p->zs_bsx;
+    a.zs_bsy = p->zs_bsy; a.zs_bsstat = p->zs_bsstat;
+    if ((p->zs_add & 3) || (p->zs_add2 & 3) || (p->zs_bsx & 3) || (p->zs_bsy & 3)) return CORRIF_EUNSUPPORTED;
     if (p->stats_part) {
-        if (p->Z != 1 || p->stats_rows_per_group <= 0 || p->stats_rows_per_group > p->M || (p->M % p->stats_rows_per_group)) return CORRIF_EINVAL;
+        if ((p->Z != 1 && (p->Zi != 1 || p->stats_rows_per_group != p->M)) || p->stats_rows_per_group <= 0 || p->stats_rows_per_group > p->M || (p->M % p->stats_rows_per_group)) return CORRIF_EINVAL;
         if (p->stats_rows_per_group != p->M && (p->stats_rows_per_group & 63)) return CORRIF_EUNSUPPORTED;
         if (scalar || p->out_map || p->N <= 16) return CORRIF_EUNSUPPORTED;     // only the TM = 2 tiles of gemm_fwd_kernel produce them
         a.stats_rpg = (int)p->stats_rows_per_group;
@@ -653,7 +663,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     const uint32_t zz = lin / tiles_mn, tile = lin - zz * tiles_mn;
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     int split = 0, z = 0;
-    if (p.splits > 1) split = (int)zz; else z = (int)zz;
+    if (p.splits > 1) { z = (int)zz / p.splits; split = (int)zz - z * p.splits; } else z = (int)zz;
     const int zo = z / p.Zi, zi = z - zo * p.Zi;
     const float* __restrict__ A = p.A + zo * p.sA_o + zi * p.sA_i;
     const float* __restrict__ B = p.B + zo * p.sB_o + zi * p.sB_i;
@@ -773,7 +783,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
 
     float* __restrict__ C;
     int64_t ldc;
-    if (p.splits > 1) { C = p.ws + (int64_t)split * p.M * p.N; ldc = p.N; }
+    if (p.splits > 1) { C = p.ws + ((int64_t)z * p.splits + split) * p.M * p.N; ldc = p.N; }
     else { C = p.C + zo * p.sC_o + zi * p.sC_i; ldc = p.ldc; }
 #pragma unroll
     for (int jj = 0; jj < TN; ++jj) {
@@ -791,10 +801,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
 
 // out[i] = sum_j ws[j*n + i] in a fixed order: block = 64 consecutive elements x 4 slab lanes (coalesced 256-B rows)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t n, int count,
-                                                          int N, int64_t ldc) {
+                                                          int N, int64_t ldc, int64_t out_zstride) {
     __shared__ float red[4][64];
     const int e = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + e;
+    ws += (int64_t)blockIdx.y * count * n;          // blockIdx.y = batch index of a grouped weight gradient (slabs ws[z][split][n])
+    out += (int64_t)blockIdx.y * out_zstride;
     float s = 0.f;
     if (i < n)
         for (int j = rl; j < count; j += 4) s += ws[(int64_t)j * n + i];
@@ -812,8 +824,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 // reduction.  Cost model: time ~ flops / (fill x 85 TFLOP/s) + 2 x splits x M x N x 4 B / 3 TB/s; the split count with the smallest
 // estimate wins (it used to be ceil(2048 / tiles): 1.6 waves of workgroups for most encoder shapes, e.g. 2088 workgroups on 1280 slots
 // for the e4 3x3 gradients; measured 60 -> 73 TF/s on the e2 1x1 gradient, 82 -> 87 on e4's, whole step -0.5 %).
-static int pick_splits(int R, int M, int N, int BM, int BN) {
-    const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+static int pick_splits(int R, int M, int N, int BM, int BN, int Z) {
+    const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * (Z > 1 ? Z : 1);
     int64_t maxs = R / 256;                 // at least 8 K-tiles of work per split
     if (maxs < 1) maxs = 1;
     if (maxs > 4096) maxs = 4096;
@@ -836,19 +848,19 @@ static void wgrad_tile(int M, int N, int& BM, int& BN) {
 
 extern "C" size_t corrif_wgrad_workspace(const CorrifWgrad* p) {
     if (!p || p->splits <= 1) return 0;
-    return (size_t)p->splits * (size_t)p->M * (size_t)p->N * sizeof(float);
+    return (size_t)(p->Z > 1 ? p->Z : 1) * (size_t)p->splits * (size_t)p->M * (size_t)p->N * sizeof(float);
 }
-extern "C" int corrif_wgrad_plan(int32_t R, int32_t M, int32_t N) {
+extern "C" int corrif_wgrad_plan(int32_t R, int32_t M, int32_t N, int32_t Z) {
     int BM, BN;
     wgrad_tile(M, N, BM, BN);
     if (BN == 256) BM = 16;
-    return pick_splits(R, M, N, BM, BN);
+    return pick_splits(R, M, N, BM, BN, Z);
 }
 
 extern "C" int corrif_slab_reduce(const float* ws, float* out, int64_t n, int32_t count, void* stream) {
     if (!ws || !out || n <= 0 || count <= 0) return CORRIF_EINVAL;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, ws, out, n,
-                       count, 0, (int64_t)0);
+                       count, 0, (int64_t)0, (int64_t)0);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
@@ -863,15 +875,15 @@ extern "C" int corrif_wgrad(const CorrifWgrad* p, void* stream) {
         return CORRIF_EUNSUPPORTED;
     if (scalar && p->g.is_gemm) return CORRIF_EUNSUPPORTED;
     if (((uintptr_t)p->A & 15) || (p->sA_o & 3) || (p->sA_i & 3)) return CORRIF_EUNSUPPORTED;
-    if (p->splits > 1 && (p->Z != 1 || !p->ws)) return CORRIF_EINVAL;
+    if (p->splits > 1 && (!p->ws || (p->Z != 1 && p->Zi != 1))) return CORRIF_EINVAL;
     if (!geom_ok(p->g)) return CORRIF_EINVAL;
     if (!p->g.is_gemm && !scalar && p->N != p->g.kd * p->g.kh * p->g.kw * p->Cs) return CORRIF_EINVAL;
     if (scalar && (p->g.ntaps <= 0 || p->g.ntaps > p->g.kd * p->g.kh * p->g.kw || p->N < p->g.ntaps)) return CORRIF_EINVAL;
-    if (p->Z > 65535 || p->splits > 65535) return CORRIF_EUNSUPPORTED;
+    if (p->Z > 65535 || p->splits > 65535 || (int64_t)p->Z * p->splits > 65535) return CORRIF_EUNSUPPORTED;
     WgradArgs a;
     a.A = p->A; a.B = p->B; a.C = p->C; a.ws = p->ws;
     a.lda = p->lda; a.ldb = p->ldb; a.ldc = p->ldc;
-    a.R = p->R; a.M = p->M; a.N = p->N; a.Cs = p->Cs; a.splits = p->splits; a.Zi = p->Zi;
+    a.R = p->R; a.M = p->M; a.N = p->N; a.Cs = p->Cs; a.splits = p->splits; a.Zi = p->Zi; a.Z = p->Z;
     int rps = (p->R + p->splits - 1) / p->splits;
     a.rows_per_split = (rps + 31) / 32 * 32;
     a.sA_o = p->sA_o; a.sA_i = p->sA_i; a.sB_o = p->sB_o; a.sB_i = p->sB_i; a.sC_o = p->sC_o; a.sC_i = p->sC_i;
@@ -882,7 +894,7 @@ extern "C" int corrif_wgrad(const CorrifWgrad* p, void* stream) {
     if (scalar) { BM = 64; BN = 128; }
     if (BN == 256) BM = 16;
     uint32_t tiles = (uint32_t)((p->M + BM - 1) / BM) * (uint32_t)((p->N + BN - 1) / BN);
-    const uint32_t nz = (uint32_t)(p->splits > 1 ? p->splits : p->Z);
+    const uint32_t nz = (uint32_t)(p->splits > 1 ? p->splits * p->Z : p->Z);
     if ((uint64_t)tiles * nz >= (1ull << 31)) return CORRIF_EUNSUPPORTED;
     dim3 grid(tiles * nz, 1, 1);
     if (scalar) {
@@ -904,8 +916,8 @@ extern "C" int corrif_wgrad(const CorrifWgrad* p, void* stream) {
     CORRIF_CHECK_LAUNCH();
     if (p->splits > 1) {
         int64_t n = (int64_t)p->M * p->N;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, p->ws, p->C, n, p->splits,
-                           p->N, p->ldc);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)p->Z), dim3(256), 0, s, p->ws, p->C, n, p->splits,
+                           p->N, p->ldc, p->sC_o);
         CORRIF_CHECK_LAUNCH();
     }
     return CORRIF_OK;

@@ -21,6 +21,9 @@ struct GemmArgs {
     // backward statistics of the BatchNorm that produced this GEMM's input (data-gradient launches): with bs_x set, stats_part receives
     // per column and 64-row block (sum g', sum g' * xhat), g' = the value this epilogue stores masked by bs_y > 0, xhat = (bs_x - mean) * rstd
     const float* bs_x; int64_t bs_ldx; const float* bs_y; int64_t bs_ldy; const float* bs_mean; const float* bs_rstd;
+    // grouped launches (Z = the three modality encoders' identical-shape layers in ONE launch): per OUTER batch index zo the epilogue
+    // operands move by these strides (floats; zs_stats in doubles)
+    int64_t zs_bias, zs_add, zs_add2, zs_stats, zs_bsx, zs_bsy, zs_bsstat;
 };
 
 
@@ -30,6 +33,7 @@ struct WgradArgs {
     int R, M, N, Cs, splits, rows_per_split, Zi;
     int64_t sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
     DevGeom g;
+    int Z;              // batch count; with splits > 1 the grid enumerates (z, split, tile) and the slabs are ws[z][split][M][N]
 };
 
 

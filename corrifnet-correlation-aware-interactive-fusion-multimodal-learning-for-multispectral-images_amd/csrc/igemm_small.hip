@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256) void smalln_fwd_kernel(GemmArgs p) {
             const int col = g * 4;
             if (col >= p.N) continue;
             f32x4 v = acc[g];
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
-            if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + (int64_t)row * p.ld_add + col);
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + zo * p.zs_bias + col);
+            if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + zo * p.zs_add + (int64_t)row * p.ld_add + col);
             if (p.act == CORRIF_ACT_RELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void smalln_fwd_kernel(GemmArgs p) {
 }
 
 int launch_smalln_fwd(const GemmArgs& a, int Z, hipStream_t s) {
-    if (a.bias && ((uintptr_t)a.bias & 15)) return CORRIF_EUNSUPPORTED;
+    if (a.bias && (((uintptr_t)a.bias & 15) || (a.zs_bias & 3))) return CORRIF_EUNSUPPORTED;
     dim3 grid((unsigned)((a.M + 255) / 256), 1, Z);
     const int ng = (a.N + 3) / 4;
     if (ng == 1) hipLaunchKernelGGL((smalln_fwd_kernel<1>), grid, dim3(256), 0, s, a);
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void smallm_wgrad_kernel(WgradArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * BN;
     int split = 0, z = 0;
-    if (p.splits > 1) split = blockIdx.z; else z = blockIdx.z;
+    if (p.splits > 1) { z = blockIdx.z / p.splits; split = blockIdx.z - z * p.splits; } else z = blockIdx.z;
     const int zo = z / p.Zi, zi = z - zo * p.Zi;
     const float* __restrict__ A = p.A + zo * p.sA_o + zi * p.sA_i;
     const float* __restrict__ B = p.B + zo * p.sB_o + zi * p.sB_i;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void smallm_wgrad_kernel(WgradArgs p) {
     }
     float* __restrict__ C;
     int64_t ldc;
-    if (p.splits > 1) { C = p.ws + (int64_t)split * p.M * p.N; ldc = p.N; }
+    if (p.splits > 1) { C = p.ws + ((int64_t)z * p.splits + split) * p.M * p.N; ldc = p.N; }
     else { C = p.C + zo * p.sC_o + zi * p.sC_i; ldc = p.ldc; }
     const int col = n0 + xcol;
     if (col < p.N) {

@@ -215,6 +215,24 @@ extern "C" int corrif_copy2d(const float* src, int64_t lds, float* dst, int64_t 
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
+// dst[g][i] = src_g[i]: the parameter tensors of G same-shaped modules gathered into one stacked buffer (grouped launches), one launch
+struct GroupPtrs { const float* p[4]; };
+__global__ void stack_groups_kernel(GroupPtrs src, float* __restrict__ dst, int64_t n) {
+    const int g = blockIdx.y;
+    const float* __restrict__ s = g == 0 ? src.p[0] : g == 1 ? src.p[1] : g == 2 ? src.p[2] : src.p[3];
+    float* __restrict__ d = dst + (int64_t)g * n;
+    GRID_STRIDE(i, n) d[i] = s[i];
+}
+extern "C" int corrif_stack_groups(const float* const* srcs, int32_t G, float* dst, int64_t n, void* stream) {
+    if (!srcs || !dst || G < 1 || G > 4 || n <= 0) return CORRIF_EINVAL;
+    GroupPtrs gp;
+    for (int i = 0; i < 4; ++i) gp.p[i] = i < G ? srcs[i] : nullptr;
+    for (int i = 0; i < G; ++i)
+        if (!gp.p[i]) return CORRIF_EINVAL;
+    hipLaunchKernelGGL(stack_groups_kernel, dim3(nblocks(n), (unsigned)G), dim3(256), 0, (hipStream_t)stream, gp, dst, n);
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}
 __global__ void sum_groups_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t ge, int groups) {
     GRID_STRIDE(i, ge) {
         float s = 0.f;

@@ -102,10 +102,10 @@ __device__ __forceinline__ void wave_sum2(double& a, double& b) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
 }
+struct RunPtrs { float* mean[4]; float* var[4]; };     // running statistics of up to 4 groups (grouped BatchNorm: one nn.BatchNorm3d per group)
 __global__ __launch_bounds__(256) void norm_stats_final_kernel(const double* __restrict__ part, int chunks, int G, int C,
                                                                int64_t rows_per_group, float eps, float* __restrict__ mean,
-                                                               float* __restrict__ rstd, float* running_mean, float* running_var,
-                                                               float momentum) {
+                                                               float* __restrict__ rstd, RunPtrs run, float momentum) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= G * C) return;
@@ -120,7 +120,10 @@ __global__ __launch_bounds__(256) void norm_stats_final_kernel(const double* __r
     if (var < 0) var = 0;
     mean[i] = (float)m;
     rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {   // G == 1 ; momentum update with the unbiased variance (nn.BatchNorm3d training)
+    if (run.mean[0]) {   // G <= 4 ; momentum update with the unbiased variance (nn.BatchNorm3d training)
+        const int gi = i / C;              // explicit selects: a dynamic index into the by-value struct would go through scratch
+        float* const running_mean = gi == 0 ? run.mean[0] : gi == 1 ? run.mean[1] : gi == 2 ? run.mean[2] : run.mean[3];
+        float* const running_var = gi == 0 ? run.var[0] : gi == 1 ? run.var[1] : gi == 2 ? run.var[2] : run.var[3];
         double unb = rows_per_group > 1 ? var * (double)rows_per_group / (double)(rows_per_group - 1) : var;
         running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
         running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
@@ -129,7 +132,8 @@ __global__ __launch_bounds__(256) void norm_stats_final_kernel(const double* __r
 
 // sums[(g*C + c)*2 + {0,1}] = (sum g, sum g*xhat) ; optional dgamma/dbeta ; colsum (bias gradient)
 __global__ __launch_bounds__(256) void norm_bwd_final_kernel(const double* __restrict__ part, int chunks, int G, int C,
-                                                             float* __restrict__ sums, float* dgamma, float* dbeta, float* colsum) {
+                                                             float* __restrict__ sums, float* dgamma, float* dbeta, float* colsum,
+                                                             int per_group) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= G * C) return;
@@ -140,9 +144,10 @@ __global__ __launch_bounds__(256) void norm_bwd_final_kernel(const double* __res
     wave_sum2(s, q);
     if (lane != 0) return;
     if (sums) { sums[i * 2] = (float)s; sums[i * 2 + 1] = (float)q; }
-    if (dgamma) dgamma[c] = (float)q;
-    if (dbeta) dbeta[c] = (float)s;
-    if (colsum) colsum[c] = (float)s;
+    const int oc = per_group ? i : c;        // per-group affine parameters / column sums: [G][C]
+    if (dgamma) dgamma[oc] = (float)q;
+    if (dbeta) dbeta[oc] = (float)s;
+    if (colsum) colsum[oc] = (float)s;
 }
 
 __global__ void eval_rstd_kernel(const float* __restrict__ var, float eps, float* __restrict__ rstd, int C) {
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ res, int64_t ldr,
                                                          float* __restrict__ y, int64_t ldy, int64_t rows_per_group, int C, int flags,
-                                                         ApplyGeo a) {
+                                                         ApplyGeo a, int64_t ags) {
     const int tid = threadIdx.x, cl = tid % a.CT, rl = tid / a.CT;
     const int c4 = blockIdx.y * a.CT + cl, g = blockIdx.z;
     if (rl >= a.RL || c4 >= a.C4) return;
@@ -182,8 +187,8 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (int64_t)g * C + c4 * 4);
     const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + (int64_t)g * C + c4 * 4);
     f32x4 ga = {1, 1, 1, 1}, be = {0, 0, 0, 0};
-    if (gamma) ga = *reinterpret_cast<const f32x4*>(gamma + c4 * 4);
-    if (beta) be = *reinterpret_cast<const f32x4*>(beta + c4 * 4);
+    if (gamma) ga = *reinterpret_cast<const f32x4*>(gamma + g * ags + c4 * 4);
+    if (beta) be = *reinterpret_cast<const f32x4*>(beta + g * ags + c4 * 4);
     for (int64_t r = r0 + rl; r < r1; r += a.RL) {
         const int64_t row = (int64_t)g * rows_per_group + r;
         f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ldx + c4 * 4);
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ gamma, const float* __restrict__ sums,
                                                              float* __restrict__ dx, int64_t lddx, float* __restrict__ dres,
                                                              int64_t lddres, int64_t rows_per_group, int C, int flags, int frozen,
-                                                             ApplyGeo a) {
+                                                             ApplyGeo a, int64_t ags) {
     const int tid = threadIdx.x, cl = tid % a.CT, rl = tid / a.CT;
     const int c4 = blockIdx.y * a.CT + cl, g = blockIdx.z;
     if (rl >= a.RL || c4 >= a.C4) return;
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const float* __rest
     if (dx) {
         mu = *reinterpret_cast<const f32x4*>(mean + (int64_t)g * C + c4 * 4);
         rs = *reinterpret_cast<const f32x4*>(rstd + (int64_t)g * C + c4 * 4);
-        if (gamma) ga = *reinterpret_cast<const f32x4*>(gamma + c4 * 4);
+        if (gamma) ga = *reinterpret_cast<const f32x4*>(gamma + g * ags + c4 * 4);
         if (!frozen) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -266,12 +271,25 @@ static bool norm_args_ok(int64_t rows_per_group, int G, int C) {
 }
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-extern "C" int corrif_norm_stats(const float* x, int64_t ldx, int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, float eps,
-                                 float* mean, float* rstd, float* running_mean, float* running_var, float momentum, double* ws,
-                                 void* stream) {
+static int run_ptrs(RunPtrs& r, float* const* rm, float* const* rv, int G) {
+    for (int i = 0; i < 4; ++i) { r.mean[i] = nullptr; r.var[i] = nullptr; }
+    if (!rm) return CORRIF_OK;
+    if (!rv || G > 4) return CORRIF_EINVAL;
+    for (int i = 0; i < G; ++i) {
+        if (!rm[i] || !rv[i]) return CORRIF_EINVAL;
+        r.mean[i] = rm[i];
+        r.var[i] = rv[i];
+    }
+    return CORRIF_OK;
+}
+
+extern "C" int corrif_norm_stats_g(const float* x, int64_t ldx, int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, float eps,
+                                   float* mean, float* rstd, float* const* running_means, float* const* running_vars, float momentum,
+                                   double* ws, void* stream) {
     if (!x || !mean || !rstd || !ws || !norm_args_ok(rows_per_group, G, C)) return CORRIF_EINVAL;
     if ((ldx & 3) || !al16(x)) return CORRIF_EUNSUPPORTED;
-    if (running_mean && (G != 1 || !running_var)) return CORRIF_EINVAL;
+    RunPtrs run;
+    if (run_ptrs(run, running_means, running_vars, G) != CORRIF_OK) return CORRIF_EINVAL;
     NormGeo n = norm_geo(rows_per_group, G, C);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL((norm_partial_kernel<0>), dim3(n.chunks, n.ctiles, G), dim3(256), 0, s, x, ldx, (const float*)nullptr, (int64_t)0,
@@ -279,19 +297,34 @@ extern "C" int corrif_norm_stats(const float* x, int64_t ldx, int64_t rows_per_g
                        (int)flags, n);
     CORRIF_CHECK_LAUNCH();
     hipLaunchKernelGGL(norm_stats_final_kernel, dim3((G * C + 3) / 4), dim3(256), 0, s, (const double*)ws, n.chunks, (int)G, (int)C,
-                       rows_per_group, eps, mean, rstd, running_mean, running_var, momentum);
+                       rows_per_group, eps, mean, rstd, run, momentum);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
-
-extern "C" int corrif_norm_stats_finalize(const double* part, int32_t chunks, int32_t G, int32_t C, int64_t rows_per_group, float eps, float* mean,
-                                          float* rstd, float* running_mean, float* running_var, float momentum, void* stream) {
-    if (!part || !mean || !rstd || chunks <= 0 || !norm_args_ok(rows_per_group, G, C)) return CORRIF_EINVAL;
+extern "C" int corrif_norm_stats(const float* x, int64_t ldx, int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, float eps,
+                                 float* mean, float* rstd, float* running_mean, float* running_var, float momentum, double* ws,
+                                 void* stream) {
     if (running_mean && (G != 1 || !running_var)) return CORRIF_EINVAL;
+    return corrif_norm_stats_g(x, ldx, rows_per_group, G, C, flags, eps, mean, rstd, running_mean ? &running_mean : nullptr,
+                               running_mean ? &running_var : nullptr, momentum, ws, stream);
+}
+
+extern "C" int corrif_norm_stats_finalize_g(const double* part, int32_t chunks, int32_t G, int32_t C, int64_t rows_per_group, float eps,
+                                            float* mean, float* rstd, float* const* running_means, float* const* running_vars,
+                                            float momentum, void* stream) {
+    if (!part || !mean || !rstd || chunks <= 0 || !norm_args_ok(rows_per_group, G, C)) return CORRIF_EINVAL;
+    RunPtrs run;
+    if (run_ptrs(run, running_means, running_vars, G) != CORRIF_OK) return CORRIF_EINVAL;
     hipLaunchKernelGGL(norm_stats_final_kernel, dim3((G * C + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, (int)chunks, (int)G, (int)C,
-                       rows_per_group, eps, mean, rstd, running_mean, running_var, momentum);
+                       rows_per_group, eps, mean, rstd, run, momentum);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
+}
+extern "C" int corrif_norm_stats_finalize(const double* part, int32_t chunks, int32_t G, int32_t C, int64_t rows_per_group, float eps, float* mean,
+                                          float* rstd, float* running_mean, float* running_var, float momentum, void* stream) {
+    if (running_mean && (G != 1 || !running_var)) return CORRIF_EINVAL;
+    return corrif_norm_stats_finalize_g(part, chunks, G, C, rows_per_group, eps, mean, rstd, running_mean ? &running_mean : nullptr,
+                                        running_mean ? &running_var : nullptr, momentum, stream);
 }
 
 extern "C" int corrif_norm_eval_rstd(const float* running_var, float eps, float* rstd, int32_t C, void* stream) {
@@ -301,31 +334,36 @@ extern "C" int corrif_norm_eval_rstd(const float* running_var, float eps, float*
     return CORRIF_OK;
 }
 
-extern "C" int corrif_norm_apply(const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
-                                 const float* beta, const float* residual, int64_t ldr, float* y, int64_t ldy,
-                                 int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, void* stream) {
+extern "C" int corrif_norm_apply_g(const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
+                                   const float* beta, const float* residual, int64_t ldr, float* y, int64_t ldy,
+                                   int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, int64_t affine_gstride, void* stream) {
     if (!x || !mean || !rstd || !y || !norm_args_ok(rows_per_group, G, C)) return CORRIF_EINVAL;
     if ((ldx & 3) || (ldy & 3) || (ldr & 3) || !al16(x) || !al16(y) || !al16(residual) || !al16(mean) || !al16(rstd) ||
-        !al16(gamma) || !al16(beta))
+        !al16(gamma) || !al16(beta) || (affine_gstride & 3))
         return CORRIF_EUNSUPPORTED;
     int nblk, ctiles;
     ApplyGeo a = apply_geo(rows_per_group, C, nblk, ctiles);
     hipLaunchKernelGGL(norm_apply_kernel, dim3(nblk, ctiles, G), dim3(256), 0, (hipStream_t)stream, x, ldx, mean, rstd, gamma, beta,
-                       residual, ldr, y, ldy, rows_per_group, (int)C, (int)flags, a);
+                       residual, ldr, y, ldy, rows_per_group, (int)C, (int)flags, a, affine_gstride);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
+extern "C" int corrif_norm_apply(const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
+                                 const float* beta, const float* residual, int64_t ldr, float* y, int64_t ldy,
+                                 int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, void* stream) {
+    return corrif_norm_apply_g(x, ldx, mean, rstd, gamma, beta, residual, ldr, y, ldy, rows_per_group, G, C, flags, 0, stream);
+}
 
-extern "C" int corrif_norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
-                               const float* mean, const float* rstd, const float* gamma, float* dx, int64_t lddx, float* dres,
-                               int64_t lddres, float* dgamma, float* dbeta, int64_t rows_per_group, int32_t G, int32_t C,
-                               int32_t flags, int32_t frozen, double* ws, void* stream) {
+extern "C" int corrif_norm_bwd_g(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                                 const float* mean, const float* rstd, const float* gamma, float* dx, int64_t lddx, float* dres,
+                                 int64_t lddres, float* dgamma, float* dbeta, int64_t rows_per_group, int32_t G, int32_t C,
+                                 int32_t flags, int32_t frozen, int64_t affine_gstride, double* ws, void* stream) {
     if (!dy || !norm_args_ok(rows_per_group, G, C) || !ws) return CORRIF_EINVAL;
     if ((flags & CORRIF_NORM_RELU_OUT) && !y) return CORRIF_EINVAL;
     if (dx && (!x || !mean || !rstd)) return CORRIF_EINVAL;
-    if ((dgamma || dbeta) && (G != 1 || !x || !mean || !rstd)) return CORRIF_EINVAL;
+    if ((dgamma || dbeta) && ((G != 1 && affine_gstride != C) || !x || !mean || !rstd)) return CORRIF_EINVAL;
     if ((lddy & 3) || (ldy & 3) || (ldx & 3) || (lddx & 3) || (lddres & 3) || !al16(dy) || !al16(y) || !al16(x) || !al16(dx) ||
-        !al16(dres) || !al16(mean) || !al16(rstd) || !al16(gamma))
+        !al16(dres) || !al16(mean) || !al16(rstd) || !al16(gamma) || (affine_gstride & 3))
         return CORRIF_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     NormGeo n = norm_geo(rows_per_group, G, C);
@@ -337,56 +375,76 @@ extern "C" int corrif_norm_bwd(const float* dy, int64_t lddy, const float* y, in
                            rows_per_group, (int)C, (int)flags, n);
         CORRIF_CHECK_LAUNCH();
         hipLaunchKernelGGL(norm_bwd_final_kernel, dim3((G * C + 3) / 4), dim3(256), 0, s, (const double*)ws, n.chunks, (int)G, (int)C,
-                           sums, dgamma, dbeta, (float*)nullptr);
+                           sums, dgamma, dbeta, (float*)nullptr, affine_gstride ? 1 : 0);
         CORRIF_CHECK_LAUNCH();
     }
     if (dx || dres) {
         int nblk, ctiles;
         ApplyGeo a = apply_geo(rows_per_group, C, nblk, ctiles);
         hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(nblk, ctiles, G), dim3(256), 0, s, dy, lddy, y, ldy, x, ldx, mean, rstd, gamma,
-                           (const float*)sums, dx, lddx, dres, lddres, rows_per_group, (int)C, (int)flags, (int)frozen, a);
+                           (const float*)sums, dx, lddx, dres, lddres, rows_per_group, (int)C, (int)flags, (int)frozen, a, affine_gstride);
         CORRIF_CHECK_LAUNCH();
     }
     return CORRIF_OK;
 }
+extern "C" int corrif_norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                               const float* mean, const float* rstd, const float* gamma, float* dx, int64_t lddx, float* dres,
+                               int64_t lddres, float* dgamma, float* dbeta, int64_t rows_per_group, int32_t G, int32_t C,
+                               int32_t flags, int32_t frozen, double* ws, void* stream) {
+    return corrif_norm_bwd_g(dy, lddy, y, ldy, x, ldx, mean, rstd, gamma, dx, lddx, dres, lddres, dgamma, dbeta, rows_per_group, G, C, flags,
+                             frozen, 0, ws, stream);
+}
 
+extern "C" int corrif_norm_bwd_pre_g(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx, const float* mean,
+                                     const float* rstd, const float* gamma, float* dx, int64_t lddx, float* dres, int64_t lddres, float* dgamma,
+                                     float* dbeta, int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, int64_t affine_gstride,
+                                     const double* part, int32_t chunks, double* ws, void* stream) {
+    if (!dy || !x || !mean || !rstd || !part || chunks <= 0 || !ws || !norm_args_ok(rows_per_group, G, C)) return CORRIF_EINVAL;
+    if ((flags & CORRIF_NORM_RELU_OUT) && !y) return CORRIF_EINVAL;
+    if (G != 1 && affine_gstride != C) return CORRIF_EINVAL;
+    if ((lddy & 3) || (ldy & 3) || (ldx & 3) || (lddx & 3) || (lddres & 3) || !al16(dy) || !al16(y) || !al16(x) || !al16(dx) ||
+        !al16(dres) || !al16(mean) || !al16(rstd) || !al16(gamma) || (affine_gstride & 3))
+        return CORRIF_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    float* sums = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(norm_bwd_final_kernel, dim3((G * C + 3) / 4), dim3(256), 0, s, part, (int)chunks, (int)G, (int)C, sums, dgamma, dbeta,
+                       (float*)nullptr, affine_gstride ? 1 : 0);
+    CORRIF_CHECK_LAUNCH();
+    if (dx || dres) {
+        int nblk, ctiles;
+        ApplyGeo a = apply_geo(rows_per_group, C, nblk, ctiles);
+        hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(nblk, ctiles, G), dim3(256), 0, s, dy, lddy, y, ldy, x, ldx, mean, rstd, gamma,
+                           (const float*)sums, dx, lddx, dres, lddres, rows_per_group, (int)C, (int)flags, 0, a, affine_gstride);
+        CORRIF_CHECK_LAUNCH();
+    }
+    return CORRIF_OK;
+}
 extern "C" int corrif_norm_bwd_pre(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx, const float* mean,
                                    const float* rstd, const float* gamma, float* dx, int64_t lddx, float* dres, int64_t lddres, float* dgamma,
                                    float* dbeta, int64_t rows, int32_t C, int32_t flags, const double* part, int32_t chunks, double* ws,
                                    void* stream) {
-    if (!dy || !x || !mean || !rstd || !part || chunks <= 0 || !ws || !norm_args_ok(rows, 1, C)) return CORRIF_EINVAL;
-    if ((flags & CORRIF_NORM_RELU_OUT) && !y) return CORRIF_EINVAL;
-    if ((lddy & 3) || (ldy & 3) || (ldx & 3) || (lddx & 3) || (lddres & 3) || !al16(dy) || !al16(y) || !al16(x) || !al16(dx) ||
-        !al16(dres) || !al16(mean) || !al16(rstd) || !al16(gamma))
-        return CORRIF_EUNSUPPORTED;
-    hipStream_t s = (hipStream_t)stream;
-    float* sums = reinterpret_cast<float*>(ws);
-    hipLaunchKernelGGL(norm_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, (int)chunks, 1, (int)C, sums, dgamma, dbeta, (float*)nullptr);
-    CORRIF_CHECK_LAUNCH();
-    if (dx || dres) {
-        int nblk, ctiles;
-        ApplyGeo a = apply_geo(rows, C, nblk, ctiles);
-        hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(nblk, ctiles, 1), dim3(256), 0, s, dy, lddy, y, ldy, x, ldx, mean, rstd, gamma,
-                           (const float*)sums, dx, lddx, dres, lddres, rows, (int)C, (int)flags, 0, a);
-        CORRIF_CHECK_LAUNCH();
-    }
-    return CORRIF_OK;
+    return corrif_norm_bwd_pre_g(dy, lddy, y, ldy, x, ldx, mean, rstd, gamma, dx, lddx, dres, lddres, dgamma, dbeta, rows, 1, C, flags, 0, part,
+                                 chunks, ws, stream);
 }
 
 // column sums (bias gradients): the statistics partial pass (sum, sum^2) + the wave-per-channel final
 extern "C" size_t corrif_col_sum_workspace(int64_t rows, int32_t C) { return corrif_norm_workspace(rows, 1, C); }
-extern "C" int corrif_col_sum(const float* x, int64_t ld, int64_t rows, int32_t C, float* out, double* ws, void* stream) {
-    if (!x || !out || !ws || !norm_args_ok(rows, 1, C)) return CORRIF_EINVAL;
+/* out[g][c] = sum over the rows of group g (G groups of `rows` consecutive rows each) */
+extern "C" int corrif_col_sum_g(const float* x, int64_t ld, int64_t rows, int32_t G, int32_t C, float* out, double* ws, void* stream) {
+    if (!x || !out || !ws || !norm_args_ok(rows, G, C)) return CORRIF_EINVAL;
     if ((ld & 3) || !al16(x)) return CORRIF_EUNSUPPORTED;
-    NormGeo n = norm_geo(rows, 1, C);
+    NormGeo n = norm_geo(rows, G, C);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL((norm_partial_kernel<0>), dim3(n.chunks, n.ctiles, 1), dim3(256), 0, s, x, ld, (const float*)nullptr, (int64_t)0,
+    hipLaunchKernelGGL((norm_partial_kernel<0>), dim3(n.chunks, n.ctiles, G), dim3(256), 0, s, x, ld, (const float*)nullptr, (int64_t)0,
                        (const float*)nullptr, (int64_t)0, (const float*)nullptr, (const float*)nullptr, ws, rows, (int)C, 0, n);
     CORRIF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(norm_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, s, (const double*)ws, n.chunks, 1, (int)C, (float*)nullptr,
-                       (float*)nullptr, (float*)nullptr, out);
+    hipLaunchKernelGGL(norm_bwd_final_kernel, dim3((G * C + 3) / 4), dim3(256), 0, s, (const double*)ws, n.chunks, (int)G, (int)C, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, out, 1);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
+}
+extern "C" int corrif_col_sum(const float* x, int64_t ld, int64_t rows, int32_t C, float* out, double* ws, void* stream) {
+    return corrif_col_sum_g(x, ld, rows, 1, C, out, ws, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

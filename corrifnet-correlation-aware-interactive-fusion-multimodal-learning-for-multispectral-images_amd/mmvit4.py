@@ -32,6 +32,7 @@ depth = 1
 num_modals = 3
 patch_size = 8
 _MODS = ("RGB", "NIR", "SWIR")
+CAPTURE_LANES = False # diagnostics: True lets a HIP-graph capture keep the sample-group lanes (see _run_lanes)
 GRAD_TAP = True       # Bottleneck identity blocks: fold the residual gradient into conv1's data-gradient epilogue (ops.grad_tap)
 
 
@@ -222,33 +223,103 @@ class Bottleneck3D(nn.Module):
     def forward(self, x, link=None):
         """link: the gradient link of this block's conv1 when the caller has parked further consumers of x on it (Encoder: the adapt
         convolution of the previous layer's output)"""
-        train = self.training
+        return _bottleneck(self, x, link, self.training)
 
-        def st():                                   # BatchNorm batch statistics come out of the producing GEMM's epilogue
-            return {"G": 1, "relu": False} if train else None
 
-        if link is None and GRAD_TAP and torch.is_grad_enabled() and x.requires_grad:
-            link = {}          # x feeds conv1 AND the residual add / the downsample conv: conv1's data-gradient epilogue absorbs their gradient
-        s1, s2, s3 = st(), st(), st()
-        # backward statistics of a BatchNorm come out of the data-gradient epilogue of the convolution that consumes its output
-        # (ops._bwd_stats_request): bn1 -> conv2, bn2 -> conv3, and the previous block's bn3 -> this block's conv1 when every other consumer
-        # of the block input rides on conv1's gradient link
-        tr = train and torch.is_grad_enabled()
-        l1, l2, l3 = ({} if tr else None), ({} if tr else None), ({} if tr else None)
-        prev = getattr(x, "_corrif_bn_link", None) if link is not None else None
-        y = self.bn1(self.conv1(x, stats=s1, grad_link=link, bwd_stats=prev), relu_out=True, pre=s1, bwd_link=l1)
-        y = self.bn2(self.conv2(y, stats=s2, bwd_stats=l1), relu_out=True, pre=s2, bwd_link=l2)
-        y = self.conv3(y, stats=s3, bwd_stats=l2)
-        xt = x if link is None else ops.grad_tap(x, link)      # created after conv1..conv3's nodes: its backward runs before theirs
-        if self.downsample is not None:                        # (the downsample path's nodes too: they are created here, not first)
-            s0 = st()
-            idt = self.downsample[1](self.downsample[0](xt, stats=s0), pre=s0)
-        else:
-            idt = xt
-        out = self.bn3(y, residual=idt, relu_out=True, pre=s3, bwd_link=l3)
-        if l3 is not None:
-            out._corrif_bn_link = l3         # read by the next block's conv1 (same tensor object)
-        return out
+def _bottleneck(L, x, link, train):
+    """Bottleneck3D.forward over a layer provider `L` (conv1, bn1, conv2, bn2, conv3, bn3, downsample): the module itself, or a
+    _GroupedBlock of the three modality encoders' twin blocks on stacked activations."""
+    G = getattr(L, "groups", 1)
+
+    def st():                                   # BatchNorm batch statistics come out of the producing GEMM's epilogue
+        return {"G": G, "relu": False} if train else None
+
+    if link is None and GRAD_TAP and torch.is_grad_enabled() and x.requires_grad:
+        link = {}          # x feeds conv1 AND the residual add / the downsample conv: conv1's data-gradient epilogue absorbs their gradient
+    s1, s2, s3 = st(), st(), st()
+    # backward statistics of a BatchNorm come out of the data-gradient epilogue of the convolution that consumes its output
+    # (ops._bwd_stats_request): bn1 -> conv2, bn2 -> conv3, and the previous block's bn3 -> this block's conv1 when every other consumer
+    # of the block input rides on conv1's gradient link
+    tr = train and torch.is_grad_enabled()
+    l1, l2, l3 = ({} if tr else None), ({} if tr else None), ({} if tr else None)
+    prev = getattr(x, "_corrif_bn_link", None) if link is not None else None
+    y = L.bn1(L.conv1(x, stats=s1, grad_link=link, bwd_stats=prev), relu_out=True, pre=s1, bwd_link=l1)
+    y = L.bn2(L.conv2(y, stats=s2, bwd_stats=l1), relu_out=True, pre=s2, bwd_link=l2)
+    y = L.conv3(y, stats=s3, bwd_stats=l2)
+    xt = x if link is None else ops.grad_tap(x, link)      # created after conv1..conv3's nodes: its backward runs before theirs
+    if L.downsample is not None:                           # (the downsample path's nodes too: they are created here, not first)
+        s0 = st()
+        idt = L.downsample[1](L.downsample[0](xt, stats=s0), pre=s0)
+    else:
+        idt = xt
+    out = L.bn3(y, residual=idt, relu_out=True, pre=s3, bwd_link=l3)
+    if l3 is not None:
+        out._corrif_bn_link = l3         # read by the next block's conv1 (same tensor object)
+    return out
+
+
+def _fire_hooks(mods, x, y, zin, zout):
+    """forward hooks of twin modules that ran as one grouped launch: each module sees its own group's input / output slice"""
+    G = len(mods)
+    for g, m in enumerate(mods):
+        if not m._forward_hooks:
+            continue
+
+        def cut(t, mode):
+            if mode == "stack":
+                n = t.shape[0] // G
+                return t[g * n:(g + 1) * n]
+            c = t.shape[-1] // G
+            return t[..., g * c:(g + 1) * c]
+        for hook in list(m._forward_hooks.values()):
+            hook(m, (cut(x, zin),), cut(y, zout))
+
+
+class _GConv:
+    """the G twin Conv3dP of the modality encoders as one grouped launch (ops.conv3d_grouped); call signature of Conv3dP.forward"""
+
+    def __init__(self, convs, zin="stack", zout="stack"):
+        self.convs, self.zin, self.zout = convs, zin, zout
+
+    def __call__(self, x, out=None, stats=None, grad_link=None, bwd_stats=None):
+        c0 = self.convs[0]
+        y = ops.conv3d_grouped(x, [c.weight for c in self.convs], [c.bias for c in self.convs], c0.stride, c0.pad, self.zin, self.zout,
+                               out, stats, grad_link, bwd_stats)
+        _fire_hooks(self.convs, x, y, self.zin, self.zout)
+        return y
+
+
+class _GBN:
+    """the G twin BatchNorm3dP on activations stacked along the batch axis; call signature of BatchNorm3dP.forward"""
+
+    def __init__(self, bns):
+        self.bns = bns
+
+    def __call__(self, x, residual=None, relu_in=False, relu_out=False, out=None, pre=None, bwd_link=None):
+        b0 = self.bns[0]
+        if b0.training:
+            for b in self.bns:
+                b._nbt_pending += 1
+        y = ops.batch_norm_grouped(x, [b.weight for b in self.bns], [b.bias for b in self.bns], [b.running_mean for b in self.bns],
+                                   [b.running_var for b in self.bns], residual, relu_in, relu_out, b0.training, b0.momentum, b0.eps, out,
+                                   pre, bwd_link)
+        _fire_hooks(self.bns, x, y, "stack", "stack")
+        return y
+
+
+class _GroupedBlock:
+    """layer provider for _bottleneck built from the twin Bottleneck3D modules of the modality encoders"""
+
+    def __init__(self, blocks):
+        self.groups = len(blocks)
+        self.blocks = blocks
+        for name in ("conv1", "conv2", "conv3"):
+            setattr(self, name, _GConv([getattr(b, name) for b in blocks]))
+        for name in ("bn1", "bn2", "bn3"):
+            setattr(self, name, _GBN([getattr(b, name) for b in blocks]))
+        self.downsample = None
+        if blocks[0].downsample is not None:
+            self.downsample = (_GConv([b.downsample[0] for b in blocks]), _GBN([b.downsample[1] for b in blocks]))
 
 
 class _ResLayer(nn.Sequential):
@@ -560,6 +631,11 @@ class MMVit4(nn.Module):
         # inter-modal correlation: run them on three HIP streams so that their small late-stage launches (e4/e5: 1-2
         # workgroups per CU each) fill the 256 CUs together.  Same kernels, same order per branch: results are unchanged.
         self.concurrent_branches = True
+        # The three encoders are the SAME network on three inputs (mmvit4.py:442-447): their twin layers run as ONE grouped launch each
+        # (stacked activations, stacked weights; _encoders_grouped) - 3x fewer, 3x larger launches whose tile grids fill the chip more
+        # evenly than three small ones.  False = one Encoder.forward per modality (the three-stream schedule of rounds 1-2).
+        self.grouped_encoders = True
+        self._gcache = None
         self.interleave_branches = True      # enqueue the three branches layer by layer in turn (diagnostics / A-B: False = branch after branch)
         self._streams = None
         # The decoder has no cross-sample coupling (InstanceNorm is per sample, no BatchNorm): run it as two half-batch chains on
@@ -638,6 +714,55 @@ class MMVit4(nn.Module):
             torch.cuda.reset_peak_memory_stats(dev)
         return plan[0]
 
+    def _encoders_grouped(self, x, cats):
+        """The three modality encoders as one stacked pass.  Returns (cat[0..5], tok): the six early-fusion concat buffers as autograd
+        tensors (the grouped adapt / conv6 convolutions write every modality's channel slice in one launch) and the encode_conv tokens
+        of all modalities stacked along the batch axis [3B, 512, 512]."""
+        encs = [getattr(self, m + "_encoder") for m in _MODS]
+        G, B = num_modals, x.shape[0]
+        if self._gcache is None:
+            gc = {"e1_bn": _GBN([e.e1_bn for e in encs]), "layers": [], "adapt": [], }
+            for name in ("e2", "e3", "e4", "e5"):
+                layers = [getattr(e, name) for e in encs]
+                gc["layers"].append((layers, [_GroupedBlock([l[i] for l in layers]) for i in range(len(layers[0]))]))
+            for l in range(5):
+                gc["adapt"].append(_GConv([getattr(e, "adapt%d" % (l + 1)) for e in encs], "stack", "cat"))
+            gc["conv6"] = _GConv([e.conv6 for e in encs], "stack", "cat")
+            gc["encode"] = _GConv([getattr(self, m + "_encode_conv") for m in _MODS], "cat", "stack")
+            self._gcache = gc
+        gc = self._gcache
+        train = self.training
+        h1, w1 = (x.shape[3] - 1) // 2 + 1, (x.shape[4] - 1) // 2 + 1
+        y0 = torch.empty((G * B, x.shape[2], h1, w1, 64), dtype=torch.float32, device=x.device)
+        parts = [encs[g].e1_c1(x[:, g], out=y0[g * B:(g + 1) * B]) for g in range(G)]        # the stems: three launches into one buffer
+        f = ops.maxpool133(gc["e1_bn"](ops.cat_batch_inplace(y0, *parts), relu_in=True))     # conv -> ReLU -> BN -> pool (mmvit4.py:172-174)
+        feats, links = [f], []
+        tap = GRAD_TAP and torch.is_grad_enabled()
+        for layers, blocks in gc["layers"]:
+            link = {} if tap and f.requires_grad else None
+            links.append(link)
+            fin = f
+            for i, blk in enumerate(blocks):
+                fprev = f
+                f = _bottleneck(blk, f, link if i == 0 else None, train)
+                _fire_hooks(blk.blocks, fprev, f, "stack", "stack")
+            _fire_hooks(layers, fin, f, "stack", "stack")
+            feats.append(f)
+        links.append(None)
+        cube = torch.empty((G * B, 8, 8, 8, basic_dims * 23), dtype=torch.float32, device=x.device)
+        outs, cparts, off = [], [], 0
+        for l, f in enumerate(feats):
+            c = _ADAPT[l][1]
+            fa = f if links[l] is None else ops.grad_tap(f, links[l])
+            xl = gc["adapt"][l](fa, out=cats[l])                                         # all three modalities' slices of the concat buffer
+            outs.append(xl)
+            cparts.append(ops.resample_groups_to_cube(xl, cube, off, c, G))              # mmvit4.py:187-191
+            off += c
+        x6 = gc["conv6"](ops.cat_channels(cube, *cparts), out=cats[5])
+        outs.append(x6)
+        tok = gc["encode"](x6).view(G * B, patch_size ** 3, transformer_basic_dims)       # channels-last == token layout (:458-461)
+        return outs, tok
+
     def _forward(self, x):
         B = x.shape[0]
         P3, T = patch_size, transformer_basic_dims
@@ -647,15 +772,23 @@ class MMVit4(nn.Module):
                 for sh, (_, c) in zip(self._level_shapes(B, x.shape[2], x.shape[3], x.shape[4]), _ADAPT)]
         cats.append(torch.empty((B, P3, P3, P3, num_modals * basic_dims * 8), dtype=torch.float32, device=x.device))
         feats, skip, qkv = [None] * 3, [None] * 3, [None] * 3
+        catf = None
+        if self.grouped_encoders:
+            catf, tok_all = self._encoders_grouped(x, cats)
+            toks = ops.split_batch(tok_all, [B * k for k in range(num_modals + 1)])
 
         def branch(i, m, interleaved):
             """one modality branch as a generator (yields between the encoder's layers and before the transformer)"""
-            enc = getattr(self, m + "_encoder")
-            if interleaved:
-                feats[i] = yield from enc.steps(x[:, i], i, cats)
+            if catf is None:
+                enc = getattr(self, m + "_encoder")
+                if interleaved:
+                    feats[i] = yield from enc.steps(x[:, i], i, cats)
+                else:
+                    feats[i] = enc(x[:, i], i, cats)
+                tok = getattr(self, m + "_encode_conv")(feats[i][5]).view(B, P3 ** 3, T)       # channels-last == token layout (:458-461)
             else:
-                feats[i] = enc(x[:, i], i, cats)
-            tok = getattr(self, m + "_encode_conv")(feats[i][5]).view(B, P3 ** 3, T)       # channels-last == token layout (:458-461)
+                feats[i] = []
+                tok = toks[i]
             skip[i] = tok
             yield
             tr = getattr(self, m + "_transformer")(tok, getattr(self, m + "_pos"))
@@ -670,9 +803,12 @@ class MMVit4(nn.Module):
                 self._edges.edge(cur, st)
                 # tensors allocated on the caller's stream that this branch reads / writes (also from its saved-for-backward
                 # state): tell the caching allocator, or their memory could be re-used while the branch stream still needs it
-                _rs(x, st)
-                for c in cats:
-                    _rs(c, st)
+                if catf is None:
+                    _rs(x, st)
+                    for c in cats:
+                        _rs(c, st)
+                else:
+                    _rs(tok_all, st)
             # The host enqueues the three branches LAYER BY LAYER in turn.  Branch after branch, the first stream ran alone while the
             # host was still enqueuing it (and, because autograd replays nodes in reverse creation order, the last stream ran alone at
             # the end of the backward while its 1/3 of the nodes were the only ones left): with interleaved creation order all three
@@ -696,8 +832,11 @@ class MMVit4(nn.Module):
             for i, m in enumerate(_MODS):
                 for _ in branch(i, m, False):
                     pass
-        fused = [getattr(self, "fusion%d" % (l + 1))(ops.cat_channels(cats[l], *[feats[i][l] for i in range(num_modals)]))
-                 for l in range(6)]            # fused[4] (fusion5) is computed and never consumed, as in the reference (:453)
+        if catf is not None:
+            fused = [getattr(self, "fusion%d" % (l + 1))(catf[l]) for l in range(6)]
+        else:
+            fused = [getattr(self, "fusion%d" % (l + 1))(ops.cat_channels(cats[l], *[feats[i][l] for i in range(num_modals)]))
+                     for l in range(6)]        # fused[4] (fusion5) is computed and never consumed, as in the reference (:453)
         corr = ops.inter_corr(qkv[0], qkv[1], qkv[2])                                      # mmvit4.py:481-503
         mm = [ops.add(skip[i], corr[i]) for i in range(num_modals)]
         mm.append(self.fused6_encode_conv(fused[5]).view(B, P3 ** 3, T))
@@ -729,7 +868,7 @@ def _run_lanes(model, tail, shared, *per_sample):
     tensor every lane reads (the positional embedding)."""
     B = per_sample[0].shape[0]
     lanes = min(int(model.decoder_split), B) if model.decoder_split else 1
-    if lanes >= 2 and torch.cuda.is_current_stream_capturing():
+    if lanes >= 2 and torch.cuda.is_current_stream_capturing() and not CAPTURE_LANES:
         # Not inside a HIP-graph capture: a captured forward with two lanes (a second fork level: capture stream -> lane stream ->
         # the decoder's skip stream) crashes the HIP runtime of ROCm 7.2 at batch >= 2 (tools/probe/graph_cases.py case C; one lane,
         # two captures on one model, batch 4 without lanes all work).  Not diagnosed; the captured schedule keeps the three branch

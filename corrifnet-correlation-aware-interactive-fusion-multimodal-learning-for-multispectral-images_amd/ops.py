@@ -66,8 +66,11 @@ STREAM_K_LONG = False     # measured (round 2): wall-neutral on the B=32 step (2
 
 
 def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, addend=None, ld_add=0, act=ACT_NONE,
-         Z=1, Zi=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), taps=None, out_map=None, stats=None, addend2=None, ld_add2=0, bstats=None):
+         Z=1, Zi=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), taps=None, out_map=None, stats=None, addend2=None, ld_add2=0, bstats=None, zs=None):
     g = H.Gemm()
+    if zs:                      # grouped launch: per-group strides of the epilogue operands (CorrifGemm.zs_*)
+        for k, v in zs.items():
+            setattr(g, "zs_" + k, int(v))
     if stats is not None:
         g.stats_part, g.stats_rows_per_group, g.stats_relu = stats
     if taps is not None:
@@ -129,7 +132,10 @@ def wgrad(A, lda, Bm, ldb, Cs, Cout, ldc, R, M, N, geom, dev, Z=1, Zi=1, sA=(0, 
     w.sB_o, w.sB_i = sB
     w.sC_o, w.sC_i = sC
     w.g = geom
-    w.splits = 1 if Z > 1 else (_old_wgrad_splits(R, M, N) if WGRAD_SPLITS_R1 else lib().corrif_wgrad_plan(R, M, N))
+    if Z > 1:                   # grouped weight gradient (Zi = 1): row splits per group; batched attention products (Zi > 1): none
+        w.splits = lib().corrif_wgrad_plan(R, M, N, Z) if Zi == 1 else 1
+    else:
+        w.splits = _old_wgrad_splits(R, M, N) if WGRAD_SPLITS_R1 else lib().corrif_wgrad_plan(R, M, N, 1)
     buf = None
     if w.splits > 1:
         buf = _ws(lib().corrif_wgrad_workspace(w), dev)
@@ -197,12 +203,13 @@ def _patch_cc(k, stride, pad, Ci, Co):
     return lib().corrif_conv3_patch_cc(Ci, Co)
 
 
-def _dgrad_parity_classes(gy, ldg, wd, gx, B, Sin, Sout, k, stride, pad, Ci, Co):
+def _dgrad_parity_classes(gy, ldg, wd, gx, B, Sin, Sout, k, stride, pad, Ci, Co, G=1, zG=0, zX=0, ldx=None):
     """Data gradient of a strided convolution without multiplying zeros.  Input voxel i receives tap t only if (i + pad - t) is a
     multiple of the stride, so the input grid splits into stride^3 parity classes, each with its own small tap subset
     (3x3 / stride 2: 1, 2, 2 and 4 taps; 1x1 / stride 2: one class with one tap, three classes with none = zeros).  One GEMM per
     class over that class's sub-grid, K = |taps| * Co, rows scattered back with the kernel's output row map.
-    wd: [T*Co, Ci] data-gradient weights (tap-major).  gx: [B, Di, Hi, Wi, Ci] is fully written."""
+    wd: [T*Co, Ci] data-gradient weights (tap-major).  gx: [B, Di, Hi, Wi, Ci] is fully written.
+    G > 1: grouped launch - wd is [G, T*Co, Ci], gy / gx move by zG / zX floats per group (B = samples per group)."""
     kd, kh, kw = k
     covered = True
     launches = []
@@ -222,11 +229,13 @@ def _dgrad_parity_classes(gy, ldg, wd, gx, B, Sin, Sout, k, stride, pad, Ci, Co)
                 launches.append((par, R, taps))
     if not covered:                                 # classes no tap can reach (1x1 stride-2: 3 of 4) keep exact zeros
         check(lib().corrif_fill(P(gx), gx.numel(), 0.0, stream()), "corrif_fill")
+    T = kd * kh * kw
     for par, R, taps in launches:
-        wc = torch.empty((len(taps) * Co, Ci), dtype=torch.float32, device=gx.device)
-        for j, t in enumerate(taps):                # gather this class's tap blocks [Co][Ci] of the tap-major weight matrix
-            check(lib().corrif_copy2d(wd.data_ptr() + 4 * t * Co * Ci, Ci, wc.data_ptr() + 4 * j * Co * Ci, Ci, Co, Ci, 0, stream()),
-                  "corrif_copy2d")
+        wc = torch.empty((G, len(taps) * Co, Ci), dtype=torch.float32, device=gx.device)
+        for gi in range(G):
+            for j, t in enumerate(taps):            # gather this class's tap blocks [Co][Ci] of the tap-major weight matrix
+                check(lib().corrif_copy2d(wd.data_ptr() + 4 * (gi * T + t) * Co * Ci, Ci, wc.data_ptr() + 4 * (gi * len(taps) + j) * Co * Ci, Ci,
+                                          Co, Ci, 0, stream()), "corrif_copy2d")
         g = H.Geom()
         g.is_gemm = 0
         g.Rd, g.Rh, g.Rw = R
@@ -236,8 +245,8 @@ def _dgrad_parity_classes(gy, ldg, wd, gx, B, Sin, Sout, k, stride, pad, Ci, Co)
         g.off_d, g.off_h, g.off_w = (par[0] + pad[0], par[1] + pad[1], par[2] + pad[2])
         g.div_d, g.div_h, g.div_w = stride
         g.dir, g.clamp, g.ntaps = -1, 0, kd * kh * kw
-        gemm(P(gy), ldg, P(wc), Ci, 1, P(gx), Ci, B * R[0] * R[1] * R[2], Ci, len(taps) * Co, Co, g, taps=taps,
-             out_map=(Sin, stride, par))
+        gemm(P(gy), ldg, P(wc), Ci, 1, P(gx), Ci if ldx is None else ldx, B * R[0] * R[1] * R[2], Ci, len(taps) * Co, Co, g, taps=taps,
+             out_map=(Sin, stride, par), Z=G, sA=(zG, 0), sB=(len(taps) * Co * Ci, 0), sC=(zX, 0))
 
 
 def _out_size(i, k, s, p):
@@ -595,6 +604,307 @@ class DepthBcastAddFn(Function):
 
 def depth_bcast_add(y, ys, f):
     return DepthBcastAddFn.apply(y, ys, f)
+
+
+# --------------------------------------------------------------------------------------- grouped (stacked-modality) operators
+# The reference runs the SAME Encoder three times, once per modality (mmvit4.py:442-447): every layer exists as three twins with identical
+# geometry and their own weights.  One launch per twin leaves the chip unevenly filled (e3 / e4 / e5 have 196 * k tiles of 128 rows: 0.77 of a
+# wave of workgroups), so the three twins run as ONE grouped launch: activations stacked along the batch axis ("stack":
+# [G*B, D, H, W, C], group g = samples [g*B, (g+1)*B)) or living side by side in a concat buffer ("cat": [B, D, H, W, G*C], group g =
+# channels [g*C, (g+1)*C) - the early-fusion buffers the adapt convolutions fill in place), weights stacked into one [G, ...] operand per step.
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def stack_nograd(tensors):
+    ts = [t.contiguous() for t in tensors]
+    out = torch.empty((len(ts),) + tuple(ts[0].shape), dtype=torch.float32, device=ts[0].device)
+    check(lib().corrif_stack_groups(_ptr_array(ts), len(ts), P(out), ts[0].numel(), stream()), "corrif_stack_groups")
+    return out
+
+
+class StackParamsFn(Function):
+    """G same-shaped parameter tensors -> one contiguous [G, ...] operand (one gather launch); backward hands each parameter its slice
+    of the stacked gradient (a view: autograd adopts it, no copy)."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        return stack_nograd(ts)
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g[i] for i in range(g.shape[0]))
+
+
+def stack_params(tensors):
+    return StackParamsFn.apply(*tensors)
+
+
+class GroupedConvFn(Function):
+    """G twin nn.Conv3d (same geometry, own weights w[g], bias b[g]) on channels-last activations as ONE launch per GEMM: forward, data
+    gradient and weight gradient run with Z = G.  Covers the encoder's layer types: 1x1x1 (stride 1 or (1,2,2)), 1x3x3 (stride 1 or
+    (1,2,2), pad (0,1,1)), zero padding, Ci > 1."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, G, zin, zout, out, stats_req, grad_link, bwd_stats):
+        _, Co, Ci, kd, kh, kw = w.shape
+        T = kd * kh * kw
+        x, _, lda = rows_view(x)
+        if zin == "stack":
+            B, (Di, Hi, Wi) = x.shape[0] // G, x.shape[1:4]
+            assert x.shape[0] == G * B and x.shape[-1] == Ci and lda == Ci
+            zA = B * Di * Hi * Wi * lda
+        else:
+            B, (Di, Hi, Wi) = x.shape[0], x.shape[1:4]
+            assert x.shape[-1] == G * Ci and T == 1 and stride == (1, 1, 1)
+            zA = Ci
+        Do, Ho, Wo = (_out_size(Di, kd, stride[0], pad[0]), _out_size(Hi, kh, stride[1], pad[1]), _out_size(Wi, kw, stride[2], pad[2]))
+        M = B * Do * Ho * Wo                                   # rows per group
+        if out is None:
+            out = torch.empty((G * B, Do, Ho, Wo, Co) if zout == "stack" else (B, Do, Ho, Wo, G * Co), dtype=torch.float32, device=x.device)
+        y, _, ldc = rows_view(out)
+        assert y is out, "conv output must be row-addressable"
+        zC = M * ldc if zout == "stack" else Co
+        is_gemm = T == 1 and stride == (1, 1, 1)
+        wp = w if T == 1 else repack(w, (G, Co, T * Ci), G * Co, Ci, T, 0, T * Ci)
+        geom = H.gemm_geom() if is_gemm else H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad)
+        st, zs = None, {"bias": Co}
+        if stats_req is not None and Co > 16:
+            chunks = (M + 63) // 64                            # BatchNorm statistics partials per group, from the epilogue
+            part = torch.empty(G * Co * chunks * 2, dtype=torch.float64, device=x.device)
+            st = (part.data_ptr(), M, 1 if stats_req["relu"] else 0)
+            zs["stats"] = Co * chunks * 2
+            stats_req["part"], stats_req["chunks"], stats_req["rpg"] = part, chunks, M
+        gemm(P(x), lda, P(wp), T * Ci, 0, P(y), ldc, M, Co, T * Ci, Ci, geom, bias=P(b) if b is not None else None, stats=st,
+             Z=G, sA=(zA, 0), sB=(Co * T * Ci, 0), sC=(zC, 0), zs=zs)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, b is not None, G, zin, zout, B, (Di, Hi, Wi), (Do, Ho, Wo), is_gemm, lda, zA)
+        ctx.grad_link, ctx.bwd_stats = grad_link, bwd_stats
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, pad, has_bias, G, zin, zout, B, (Di, Hi, Wi), (Do, Ho, Wo), is_gemm, lda, zA = ctx.cfg
+        _, Co, Ci, kd, kh, kw = w.shape
+        T = kd * kh * kw
+        gy, _, ldg = rows_view(gy)
+        dev = gy.device
+        M, Min = B * Do * Ho * Wo, B * Di * Hi * Wi
+        zG = M * ldg if zout == "stack" else Co
+        assert ldg == (Co if zout == "stack" else G * Co)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            if zin == "stack":
+                gx, ldx, zX = torch.empty((G * B, Di, Hi, Wi, Ci), dtype=torch.float32, device=dev), Ci, Min * Ci
+            else:
+                gx, ldx, zX = torch.empty((B, Di, Hi, Wi, G * Ci), dtype=torch.float32, device=dev), G * Ci, Ci
+            if is_gemm:
+                adds, link = [], ctx.grad_link
+                while link is not None and link.get("gs") and len(adds) < 2:      # gradients parked by the other consumers (grad_tap)
+                    ga, _, ld_a = rows_view(link["gs"].pop())
+                    adds.append((ga, ld_a))
+                    TAP_STATS["epilogue"] += G               # one tapped gradient per twin module
+                adds += [(None, 0)] * (2 - len(adds))
+                st, bst, zs = _bwd_stats_request_g(ctx.bwd_stats, link, Min, Ci, G, dev, x, lda) if zin == "stack" else (None, None, {})
+                if adds[0][0] is not None:
+                    zs["add"] = Min * adds[0][1]
+                if adds[1][0] is not None:
+                    zs["add2"] = Min * adds[1][1]
+                gemm(P(gy), ldg, P(w), Ci, 1, P(gx), ldx, Min, Ci, Co, Co, H.gemm_geom(), addend=P(adds[0][0]) if adds[0][0] is not None else None,
+                     ld_add=adds[0][1], addend2=P(adds[1][0]) if adds[1][0] is not None else None, ld_add2=adds[1][1], stats=st, bstats=bst,
+                     Z=G, sA=(zG, 0), sB=(Co * Ci, 0), sC=(zX, 0), zs=zs)
+            else:
+                if T == 1:
+                    wd = w
+                else:
+                    wd = torch.empty((G, T * Co, Ci), dtype=torch.float32, device=dev)
+                    for gi in range(G):                                            # tap-major data-gradient weights per group
+                        check(lib().corrif_weight_repack(P(w[gi]), P(wd[gi]), Co, Ci, T, 1, T * Ci, stream()), "corrif_weight_repack")
+                if stride != (1, 1, 1):
+                    _dgrad_parity_classes(gy, ldg, wd, gx, B, (Di, Hi, Wi), (Do, Ho, Wo), (kd, kh, kw), stride, pad, Ci, Co, G=G, zG=zG, zX=zX)
+                else:
+                    geom = H.conv_geom((Di, Hi, Wi), (Do, Ho, Wo), (kd, kh, kw), stride, pad, transposed=True)
+                    st, bst, zs = _bwd_stats_request_g(ctx.bwd_stats, ctx.grad_link, Min, Ci, G, dev, x, lda)
+                    gemm(P(gy), ldg, P(wd), Ci, 1, P(gx), Ci, Min, Ci, T * Co, Co, geom, stats=st, bstats=bst,
+                         Z=G, sA=(zG, 0), sB=(T * Co * Ci, 0), sC=(zX, 0), zs=zs)
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty(w.shape, dtype=torch.float32, device=dev)
+            if T == 1:
+                geom = H.gemm_geom() if is_gemm else H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (1, 1, 1), stride, pad)
+                wgrad(P(gy), ldg, P(x), lda, Ci, P(gw), Ci, M, Co, Ci, geom, dev, Z=G, sA=(zG, 0), sB=(zA, 0), sC=(Co * Ci, 0))
+            else:
+                gwp = torch.empty((G, Co, T * Ci), dtype=torch.float32, device=dev)
+                geom = H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad)
+                wgrad(P(gy), ldg, P(x), lda, Ci, P(gwp), T * Ci, M, Co, T * Ci, geom, dev, Z=G, sA=(zG, 0), sB=(zA, 0), sC=(Co * T * Ci, 0))
+                check(lib().corrif_weight_repack(P(gwp), P(gw), G * Co, Ci, T, 2, T * Ci, stream()), "corrif_weight_repack")
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = torch.empty((G, Co), dtype=torch.float32, device=dev)
+            if zout == "stack":
+                ws = _ws(lib().corrif_norm_workspace(M, G, Co), dev)
+                check(lib().corrif_col_sum_g(P(gy), ldg, M, G, Co, P(gb), P(ws), stream()), "corrif_col_sum_g")
+            else:                                     # concat layout: the column sums of the [M][G*Co] gradient ARE [G][Co]
+                ws = _ws(lib().corrif_col_sum_workspace(M, G * Co), dev)
+                check(lib().corrif_col_sum(P(gy), ldg, M, G * Co, P(gb), P(ws), stream()), "corrif_col_sum")
+        gx = _finish_link(ctx.grad_link, gx)
+        return gx, gw, gb, None, None, None, None, None, None, None, None, None
+
+
+def _bwd_stats_request_g(bl, grad_link, rows, C, G, dev, xin, ldin):
+    """grouped counterpart of _bwd_stats_request: returns (stats, bstats, zs strides) for ops.gemm"""
+    if not BWD_STATS or bl is None or "x" not in bl or bl["rows"] != rows or bl["C"] != C or bl.get("G") != G or C <= 16:
+        return None, None, {}
+    if grad_link is not None and (grad_link.get("gs") or grad_link.get("late")):
+        return None, None, {}
+    chunks = (rows + 63) // 64
+    part = torch.empty(G * C * chunks * 2, dtype=torch.float64, device=dev)
+    bl["part"], bl["chunks"], bl["grad_link"] = part, chunks, grad_link
+    zs = {"stats": C * chunks * 2, "bsx": rows * bl["ldx"], "bsy": rows * ldin, "bsstat": C}
+    return ((part.data_ptr(), rows, 0), (P(bl["x"]), bl["ldx"], P(xin) if bl["relu_out"] else None, ldin, P(bl["mean"]), P(bl["rstd"])), zs)
+
+
+def conv3d_grouped(x, weights, biases, stride, pad, zin="stack", zout="stack", out=None, stats=None, grad_link=None, bwd_stats=None):
+    """weights / biases: the G twin modules' parameters (lists); see GroupedConvFn"""
+    G = len(weights)
+    w = stack_params(weights)
+    b = stack_params(biases) if biases[0] is not None else None
+    return GroupedConvFn.apply(x, w, b, tuple(stride), tuple(pad), G, zin, zout, out, stats, grad_link, bwd_stats)
+
+
+class GroupedBatchNormFn(Function):
+    """G twin nn.BatchNorm3d on activations stacked along the batch axis: group g = rows [g*rpg, (g+1)*rpg) with its own statistics,
+    affine parameters gamma[g], beta[g] and running buffers.  Same arithmetic per group as BatchNormFn."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_means, running_vars, residual, flags, training, momentum, eps, out, pre, bwd_link, G):
+        x, rows, ldx = rows_view(x)
+        C = x.shape[-1]
+        rpg = rows // G
+        dev = x.device
+        rstd = torch.empty((G, C), dtype=torch.float32, device=dev)
+        if training:
+            mean = torch.empty((G, C), dtype=torch.float32, device=dev)
+            rm, rv = _ptr_array(running_means), _ptr_array(running_vars)
+            if pre is not None and "part" in pre and pre["rpg"] == rpg and bool(pre["relu"]) == bool(flags & NORM_RELU_IN):
+                check(lib().corrif_norm_stats_finalize_g(P(pre["part"]), pre["chunks"], G, C, rpg, eps, P(mean), P(rstd), rm, rv, momentum,
+                                                         stream()), "corrif_norm_stats_finalize_g")
+            else:
+                ws = _norm_ws(rpg, G, C, dev)
+                check(lib().corrif_norm_stats_g(P(x), ldx, rpg, G, C, flags, eps, P(mean), P(rstd), rm, rv, momentum, P(ws), stream()),
+                      "corrif_norm_stats_g")
+        else:
+            mean = stack_nograd(running_means)
+            var = stack_nograd(running_vars)
+            check(lib().corrif_norm_eval_rstd(P(var), eps, P(rstd), G * C, stream()), "corrif_norm_eval_rstd")
+        ldr = 0
+        if residual is not None:
+            residual, _, ldr = rows_view(residual)
+        if out is None:
+            out = torch.empty(x.shape, dtype=torch.float32, device=dev)
+        y, _, ldy = rows_view(out)
+        assert y is out
+        check(lib().corrif_norm_apply_g(P(x), ldx, P(mean), P(rstd), P(gamma), P(beta), P(residual), ldr, P(y), ldy, rpg, G, C, flags, C,
+                                        stream()), "corrif_norm_apply_g")
+        ctx.save_for_backward(x, mean, rstd, gamma, y if (flags & NORM_RELU_OUT) else None)
+        ctx.cfg = (flags, not training, residual is not None, G)
+        ctx.bwd_link = None
+        if bwd_link is not None and training and not (flags & NORM_RELU_IN) and ldy == C:
+            bwd_link.update(x=x, ldx=ldx, relu_out=bool(flags & NORM_RELU_OUT), mean=mean, rstd=rstd, rows=rpg, C=C, G=G)
+            ctx.bwd_link = bwd_link
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, mean, rstd, gamma, y = ctx.saved_tensors
+        flags, frozen, has_res, G = ctx.cfg
+        x, rows, ldx = rows_view(x)
+        gy, _, ldg = rows_view(gy)
+        C = x.shape[-1]
+        rpg = rows // G
+        dev = x.device
+        ldy = 0
+        if y is not None:
+            y, _, ldy = rows_view(y)
+        gx = torch.empty(x.shape, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        gres = torch.empty(x.shape, dtype=torch.float32, device=dev) if (has_res and ctx.needs_input_grad[5]) else None
+        ggamma = torch.empty((G, C), dtype=torch.float32, device=dev)
+        gbeta = torch.empty((G, C), dtype=torch.float32, device=dev)
+        bl = ctx.bwd_link
+        if bl is not None and "part" in bl and not frozen and not (bl.get("grad_link") or {}).get("late") and ldg == C:
+            ws = torch.empty(2 * G * C + 16, dtype=torch.float32, device=dev)
+            check(lib().corrif_norm_bwd_pre_g(P(gy), ldg, P(y), ldy, P(x), ldx, P(mean), P(rstd), P(gamma), P(gx), C, P(gres), C, P(ggamma),
+                                              P(gbeta), rpg, G, C, flags, C, P(bl.pop("part")), bl["chunks"], P(ws), stream()),
+                  "corrif_norm_bwd_pre_g")
+            NORM_BWD_STATS["epilogue"] += G
+        else:
+            ws = _norm_ws(rpg, G, C, dev)
+            check(lib().corrif_norm_bwd_g(P(gy), ldg, P(y), ldy, P(x), ldx, P(mean), P(rstd), P(gamma), P(gx), C, P(gres), C, P(ggamma),
+                                          P(gbeta), rpg, G, C, flags, 1 if frozen else 0, C, P(ws), stream()), "corrif_norm_bwd_g")
+            NORM_BWD_STATS["pass"] += G
+        return gx, ggamma, gbeta, None, None, gres, None, None, None, None, None, None, None, None
+
+
+def batch_norm_grouped(x, gammas, betas, running_means, running_vars, residual=None, relu_in=False, relu_out=False, training=True,
+                       momentum=0.1, eps=1e-5, out=None, pre=None, bwd_link=None):
+    flags = (NORM_RELU_IN if relu_in else 0) | (NORM_RELU_OUT if relu_out else 0)
+    return GroupedBatchNormFn.apply(x, stack_params(gammas), stack_params(betas), list(running_means), list(running_vars), residual, flags,
+                                    training, momentum, eps, out, pre, bwd_link, len(gammas))
+
+
+class CatBatchInPlaceFn(Function):
+    """torch.cat(dim=0) whose parts were written in place into sample ranges of `buf` by their producers (the three stems)."""
+
+    @staticmethod
+    def forward(ctx, holder, *parts):
+        ctx.ns = [p.shape[0] for p in parts]
+        buf = holder[0]
+        return buf.view(buf.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, lo = [], 0
+        for n in ctx.ns:
+            outs.append(g[lo:lo + n])
+            lo += n
+        return (None,) + tuple(outs)
+
+
+def cat_batch_inplace(buf, *parts):
+    return CatBatchInPlaceFn.apply([buf], *parts)
+
+
+class ResampleGroupsFn(Function):
+    """The encoder's five `F.interpolate(x_l, size=(8,8,8), trilinear, align_corners=True)` (mmvit4.py:187-191) for G modalities whose x_l
+    live side by side in a concat buffer [B, D, H, W, G*c]: group g is resampled into channels [off, off+c) of samples [g*B, (g+1)*B) of
+    the stacked cube [G*B, 8, 8, 8, Ctot].  Backward writes the gradient of the whole concat buffer (one slice per group)."""
+
+    @staticmethod
+    def forward(ctx, x, cube, off, c, G):
+        x, _, ldx = rows_view(x)
+        B, Di, Hi, Wi, _ = x.shape
+        Do, Ho, Wo, Ct = cube.shape[1:]
+        assert cube.is_contiguous() and cube.shape[0] == G * B and x.shape[-1] == G * c
+        for g in range(G):
+            check(lib().corrif_trilinear_fwd(x.data_ptr() + 4 * g * c, ldx, cube.data_ptr() + 4 * (g * B * Do * Ho * Wo * Ct + off), Ct,
+                                             B, c, Di, Hi, Wi, Do, Ho, Wo, stream()), "corrif_trilinear_fwd")
+        ctx.cfg = (B, Di, Hi, Wi, off, c, G)
+        return cube[..., off:off + c]
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Di, Hi, Wi, off, c, G = ctx.cfg
+        g, _, ldg = rows_view(g)
+        Do, Ho, Wo = g.shape[1:4]
+        gx = torch.empty((B, Di, Hi, Wi, G * c), dtype=torch.float32, device=g.device)
+        for gi in range(G):
+            check(lib().corrif_trilinear_bwd(g.data_ptr() + 4 * gi * B * Do * Ho * Wo * ldg, ldg, gx.data_ptr() + 4 * gi * c, G * c,
+                                             B, c, Di, Hi, Wi, Do, Ho, Wo, stream()), "corrif_trilinear_bwd")
+        return gx, None, None, None, None
+
+
+def resample_groups_to_cube(x, cube, off, c, G):
+    return ResampleGroupsFn.apply(x, cube, off, c, G)
 
 
 # --------------------------------------------------------------------------------------- linear

@@ -32,7 +32,7 @@ extern "C" {
 #define CORRIF_EUNSUPPORTED (-2)
 #define CORRIF_ELAUNCH (-3)
 
-#define CORRIF_ABI_VERSION 5   /* 2: CorrifConv3Patch.fold  3: CorrifGemm.ws / no_split (stream-K), corrif_scale, corrif_fill  4: CorrifGemm.addend2, corrif_flash_attn_*  5: CorrifGemm.bstats_*, corrif_norm_bwd_pre, corrif_stem_*, corrif_depth_* */
+#define CORRIF_ABI_VERSION 6   /* 6: grouped launches (CorrifGemm.zs_*, corrif_wgrad with Z x splits, per-group affine norms)  2: CorrifConv3Patch.fold  3: CorrifGemm.ws / no_split (stream-K), corrif_scale, corrif_fill  4: CorrifGemm.addend2, corrif_flash_attn_*  5: CorrifGemm.bstats_*, corrif_norm_bwd_pre, corrif_stem_*, corrif_depth_* */
 int corrif_abi_version(void);
 /* name of the gfx target the library was built for ("gfx950") - host-only call */
 const char* corrif_build_arch(void);
@@ -112,6 +112,12 @@ typedef struct CorrifGemm {
      * ReLU after that BatchNorm) and xhat = (bstats_x - bstats_mean) * bstats_rstd; bstats_x / bstats_y are [M][N] like C.
      * corrif_norm_bwd_pre consumes the partials: the separate reduction pass over (dy, x, y) of corrif_norm_bwd disappears. */
     const float* bstats_x; int64_t bstats_ldx; const float* bstats_y; int64_t bstats_ldy; const float* bstats_mean; const float* bstats_rstd;
+    /* grouped launch (ABI 6): the three modality encoders (mmvit4.py:442-447 runs the same `Encoder` on x[:,0], x[:,1], x[:,2]) execute
+     * their identical-shape layers as ONE launch with Z = 3 (Zi = 1).  A / B / C move by sA_o / sB_o / sC_o per group as before (stacked
+     * activations: rows * ld; a concat buffer filled in place: the group's channel offset); the epilogue operands move by these strides
+     * per outer batch index (floats; zs_stats in doubles): bias, addend, addend2, stats_part, bstats_x, bstats_y, bstats_mean / _rstd.
+     * With Z > 1 the fused statistics are per group: stats_rows_per_group must equal M. */
+    int64_t zs_bias, zs_add, zs_add2, zs_stats, zs_bsx, zs_bsy, zs_bsstat;
 } CorrifGemm;
 int corrif_gemm_fwd(const CorrifGemm* p, void* stream);
 size_t corrif_gemm_fwd_workspace(const CorrifGemm* p);   /* bytes of CorrifGemm.ws this launch needs; queries the device's CU count */
@@ -139,12 +145,12 @@ typedef struct CorrifWgrad {
     float* C; int64_t ldc;                        /* [M][N] (used directly when splits == 1) */
     float* ws;                                    /* splits*M*N floats when splits > 1       */
     int32_t R, M, N; int32_t splits;
-    int32_t Z, Zi; int64_t sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;   /* batch (splits must be 1) */
+    int32_t Z, Zi; int64_t sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;   /* batch; splits > 1 with Z > 1 (ABI 6): ws holds Z*splits slabs */
     CorrifGeom g;                                 /* rows = R enumerate g.R*, source = B     */
 } CorrifWgrad;
 int corrif_wgrad(const CorrifWgrad* p, void* stream);
 size_t corrif_wgrad_workspace(const CorrifWgrad* p);   /* bytes; host-only */
-int corrif_wgrad_plan(int32_t R, int32_t M, int32_t N);  /* recommended `splits`; host-only */
+int corrif_wgrad_plan(int32_t R, int32_t M, int32_t N, int32_t Z);  /* recommended `splits` for a launch of Z batches; host-only */
 
 /* out[i] = sum_j in[j*n + i], j < count (also used for bias gradients through col_sum) */
 int corrif_slab_reduce(const float* ws, float* out, int64_t n, int32_t count, void* stream);
@@ -246,6 +252,30 @@ int corrif_norm_bwd_pre(const float* dy, int64_t lddy, const float* y, int64_t l
                         const float* rstd, const float* gamma, float* dx, int64_t lddx, float* dres, int64_t lddres, float* dgamma,
                         float* dbeta, int64_t rows, int32_t C, int32_t flags, const double* part, int32_t chunks, double* ws, void* stream);
 size_t corrif_norm_workspace(int64_t rows_per_group, int32_t G, int32_t C);
+/* Grouped variants (ABI 6) for the three modality encoders run as one stacked pass (mmvit4.py:442-447: the same Encoder on x[:,0], x[:,1],
+ * x[:,2]): group g = modality g, rows_per_group rows each, its own nn.BatchNorm3d.  affine_gstride = C: gamma / beta / dgamma / dbeta are
+ * [G][C] (one parameter set per group); 0: shared [C] as in the plain entries.  running_means / running_vars: host arrays of G (<= 4)
+ * device pointers, one per group's module buffers, or NULL. */
+int corrif_norm_stats_g(const float* x, int64_t ldx, int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, float eps, float* mean,
+                        float* rstd, float* const* running_means, float* const* running_vars, float momentum, double* ws, void* stream);
+int corrif_norm_stats_finalize_g(const double* part, int32_t chunks, int32_t G, int32_t C, int64_t rows_per_group, float eps, float* mean,
+                                 float* rstd, float* const* running_means, float* const* running_vars, float momentum, void* stream);
+int corrif_norm_apply_g(const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                        const float* residual, int64_t ldr, float* y, int64_t ldy, int64_t rows_per_group, int32_t G, int32_t C,
+                        int32_t flags, int64_t affine_gstride, void* stream);
+int corrif_norm_bwd_g(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx, const float* mean,
+                      const float* rstd, const float* gamma, float* dx, int64_t lddx, float* dres, int64_t lddres, float* dgamma, float* dbeta,
+                      int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, int32_t frozen, int64_t affine_gstride, double* ws,
+                      void* stream);
+int corrif_norm_bwd_pre_g(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx, const float* mean,
+                          const float* rstd, const float* gamma, float* dx, int64_t lddx, float* dres, int64_t lddres, float* dgamma,
+                          float* dbeta, int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, int64_t affine_gstride,
+                          const double* part, int32_t chunks, double* ws, void* stream);
+/* out[g][c] = sum over the `rows` consecutive rows of group g (bias gradients of a grouped convolution) */
+int corrif_col_sum_g(const float* x, int64_t ld, int64_t rows, int32_t G, int32_t C, float* out, double* ws, void* stream);
+/* dst[g][0..n) = srcs[g][0..n): the weights / affine parameters of G (<= 4) same-shaped modules (the three modality encoders' twin
+ * layers, mmvit4.py:394-396) gathered into one stacked operand of a grouped launch; srcs = host array of G device pointers */
+int corrif_stack_groups(const float* const* srcs, int32_t G, float* dst, int64_t n, void* stream);
 
 /* LayerNorm over the last dim (C = 512), eps 1e-5 (mmvit4.py:327,335; aten::native_layer_norm).
  * Optional fused pre-add: xin = x + pos[row % pos_rows] (Transformer.forward `x = x + pos`,

@@ -111,6 +111,9 @@ NOGRAD_PREFIXES = ("RGB_decode_conv.", "NIR_decode_conv.", "SWIR_decode_conv.", 
 # the large BASELINE geometries at batch 2 (fixtures from the CPU oracle on the GPU box's host, tests/golden/make_golden_large.py):
 # name -> (B, bands per modality, H, W, weight seed); configs[2] = 8 bands 256^2, configs[4] = 12 bands 512^2
 LARGE_CASES = {"oracle_train_b2_d8_256": (2, 8, 256, 256, 41), "oracle_train_b2_d12_512": (2, 12, 512, 512, 42)}
+# checked against the oracle's modules evaluated on the device only (no CPU fixture): the headline geometry at the largest batch whose
+# 128^3 decoder tensors still fit ATen's 32-bit index math on a device (B = 32 does not: 32 x 32 x 128^3 elements)
+DEVICE_CASES = {"device_train_b8_d4_224": (8, 4, 224, 224, 43)}
 
 
 # the same for the sibling model MMVit2

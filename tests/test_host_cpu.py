@@ -33,12 +33,12 @@ def test_library_exports_every_declared_symbol(built):
     assert set(corrif_hip.EXPORTS) == declared           # the ctypes mirror binds exactly the header's surface
     # host-only entry points are callable without a GPU
     lib.corrif_abi_version.restype = ctypes.c_int
-    assert lib.corrif_abi_version() == 5
+    assert lib.corrif_abi_version() == 6
     lib.corrif_build_arch.restype = ctypes.c_char_p
     assert lib.corrif_build_arch() == b"gfx950"
     lib.corrif_wgrad_plan.restype = ctypes.c_int
-    assert lib.corrif_wgrad_plan(67108864, 8, 864) > 64        # huge-R, tiny-output weight gradient is split over many workgroups
-    assert lib.corrif_wgrad_plan(6272, 512, 4608) >= 1
+    assert lib.corrif_wgrad_plan(67108864, 8, 864, 1) > 64        # huge-R, tiny-output weight gradient is split over many workgroups
+    assert lib.corrif_wgrad_plan(6272, 512, 4608, 1) >= 1
 
 
 def test_ctypes_struct_layout_matches_header(built):

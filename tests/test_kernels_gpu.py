@@ -189,6 +189,111 @@ def test_batch_norm_backward_statistics_from_dgrad_epilogue(ops, kind, monkeypat
         assert rel(a, b) < 2e-6, i
 
 
+GROUPED = [
+    # name, Ci, Co, k, stride, pad, (B per group, D, H, W), bias, zin, zout
+    ("1x1_stack", 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 3, 14, 14), False, "stack", "stack"),
+    ("1x1_ragged_rows", 128, 96, (1, 1, 1), (1, 1, 1), (0, 0, 0), (3, 2, 7, 9), False, "stack", "stack"),
+    ("1x3x3", 32, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 3, 14, 14), False, "stack", "stack"),
+    ("1x3x3_stride2", 32, 48, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 3, 14, 14), False, "stack", "stack"),
+    ("1x1_stride2", 64, 96, (1, 1, 1), (1, 2, 2), (0, 0, 0), (2, 3, 14, 14), False, "stack", "stack"),
+    ("adapt_to_cat_small_n", 64, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 3, 14, 14), True, "stack", "cat"),
+    ("adapt_to_cat", 256, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 7, 7), True, "stack", "cat"),
+    ("conv6_ktail_184", 184, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 8, 8, 8), True, "stack", "cat"),
+    ("encode_from_cat", 64, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 8, 8, 8), True, "cat", "stack"),
+]
+
+
+@pytest.mark.parametrize("cfg", GROUPED, ids=[c[0] for c in GROUPED])
+def test_grouped_conv_equals_its_twins(ops, cfg):
+    """ops.conv3d_grouped (the three modality encoders' twin layers as ONE launch per GEMM, mmvit4.py:442-447) against F.conv3d per
+    group on the CPU, forward / data gradient / weight gradient / bias gradient, for every layer type and activation layout the
+    encoder uses: stacked along the batch axis, or side by side in a concat buffer."""
+    _, Ci, Co, k, stride, pad, (B, D, Hh, W), bias, zin, zout = cfg
+    G = 3
+    xs = [rnd(B, Ci, D, Hh, W, seed=40 + g) for g in range(G)]
+    ws = [rnd(Co, Ci, *k, seed=50 + g, scale=(Ci * k[0] * k[1] * k[2]) ** -0.5) for g in range(G)]
+    bs = [rnd(Co, seed=60 + g) if bias else None for g in range(G)]
+    refs = []
+    for g in range(G):
+        x, w = xs[g].clone().requires_grad_(), ws[g].clone().requires_grad_()
+        b = bs[g].clone().requires_grad_() if bias else None
+        refs.append((x, w, b, F.conv3d(x, w, b, stride, pad)))
+    gys = [rnd(*refs[g][3].shape, seed=70 + g) for g in range(G)]
+    for g in range(G):
+        refs[g][3].backward(gys[g])
+
+    def pack(ts, mode):      # NCDHW per group -> channels-last "stack" / "cat" layout
+        ts = [cl(t) for t in ts]
+        return torch.cat(ts, 0 if mode == "stack" else -1).contiguous()
+
+    def unpack(t, mode, g):
+        n = t.shape[0] // G if mode == "stack" else t.shape[-1] // G
+        return ncdhw(t[g * n:(g + 1) * n] if mode == "stack" else t[..., g * n:(g + 1) * n])
+
+    xg = pack(xs, zin).to(DEV).requires_grad_()
+    wg = [w.to(DEV).requires_grad_() for w in ws]
+    bg = [b.to(DEV).requires_grad_() if bias else None for b in bs]
+    y = ops.conv3d_grouped(xg, wg, bg, stride, pad, zin, zout)
+    y.backward(pack(gys, zout).to(DEV))
+    torch.cuda.synchronize()
+    for g in range(G):
+        x, w, b, yr = refs[g]
+        assert rel(unpack(y, zout, g), yr) < 2e-6, g
+        assert rel(unpack(xg.grad, zin, g), x.grad) < 1e-5, g
+        assert rel(wg[g].grad, w.grad) < 1e-5, g
+        if bias:
+            assert rel(bg[g].grad, b.grad) < 1e-5, g
+    # ... and bit-for-bit what the per-twin launches of the same kernels produce in the forward pass
+    if zin == "stack" and zout == "stack":
+        for g in range(G):
+            yt = ops.conv3d(cl(xs[g]).to(DEV), ws[g].to(DEV), None, stride, pad)
+            assert torch.equal(yt, y.detach()[g * B:(g + 1) * B]), g
+
+
+@pytest.mark.parametrize("relu_in,relu_out,res,C,training", [(False, True, False, 64, True), (False, True, True, 256, True),
+                                                             (True, False, False, 64, True), (False, True, True, 128, False)])
+def test_grouped_batch_norm_equals_its_twins(ops, relu_in, relu_out, res, C, training):
+    """ops.batch_norm_grouped (three twin nn.BatchNorm3d on batch-stacked activations: per-group statistics, affine parameters and
+    running buffers) against F.batch_norm per group on the CPU, forward, input / residual / affine gradients, running statistics."""
+    G, B, D, Hh, W = 3, 2, 3, 9, 11
+    xs = [rnd(B, C, D, Hh, W, seed=80 + g, scale=1.0 + g) + g for g in range(G)]
+    rs = [rnd(B, C, D, Hh, W, seed=90 + g) for g in range(G)]
+    gam = [rnd(C, seed=100 + g) * 0.3 + 1 for g in range(G)]
+    bet = [rnd(C, seed=110 + g) * 0.1 for g in range(G)]
+    rms = [rnd(C, seed=120 + g) * 0.1 for g in range(G)]
+    rvs = [rnd(C, seed=130 + g).abs() + 0.5 for g in range(G)]
+    gys = [rnd(B, C, D, Hh, W, seed=140 + g) for g in range(G)]
+    refs = []
+    for g in range(G):
+        x, r = xs[g].clone().requires_grad_(), rs[g].clone().requires_grad_()
+        ga, be = gam[g].clone().requires_grad_(), bet[g].clone().requires_grad_()
+        rm, rv = rms[g].clone(), rvs[g].clone()
+        y = F.batch_norm(F.relu(x) if relu_in else x, rm, rv, ga, be, training, 0.1, 1e-5)
+        if res:
+            y = y + r
+        if relu_out:
+            y = F.relu(y)
+        y.backward(gys[g])
+        refs.append((x, r, ga, be, rm, rv, y))
+    xg = torch.cat([cl(t) for t in xs], 0).to(DEV).requires_grad_()
+    rg = torch.cat([cl(t) for t in rs], 0).to(DEV).requires_grad_() if res else None
+    gg = [t.to(DEV).requires_grad_() for t in gam]
+    bg = [t.to(DEV).requires_grad_() for t in bet]
+    rmg, rvg = [t.to(DEV) for t in rms], [t.to(DEV) for t in rvs]
+    y = ops.batch_norm_grouped(xg, gg, bg, rmg, rvg, rg, relu_in, relu_out, training)
+    y.backward(torch.cat([cl(t) for t in gys], 0).to(DEV))
+    torch.cuda.synchronize()
+    for g in range(G):
+        x, r, ga, be, rm, rv, yr = refs[g]
+        sl = slice(g * B, (g + 1) * B)
+        assert rel(ncdhw(y[sl]), yr) < 2e-6
+        assert rel(ncdhw(xg.grad[sl]), x.grad) < 2e-5
+        if res:
+            assert rel(ncdhw(rg.grad[sl]), r.grad) < 1e-6
+        assert rel(gg[g].grad, ga.grad) < 2e-5 and rel(bg[g].grad, be.grad) < 2e-5
+        assert rel(rmg[g], rm) < 1e-6 and rel(rvg[g], rv) < 1e-6
+
+
 def test_conv3d_sliced_io(ops):
     """input is a channel slice of a wider buffer and the output is written into a slice (in-place concat)."""
     B, D, Hh, W, Ci, Co = 2, 3, 6, 6, 16, 24
@@ -503,8 +608,11 @@ def test_flash_attention_matches_materialised_at_2048_tokens(ops, monkeypatch):
         assert rel(g1[..., sl], g2[..., sl]) < 2e-5
 
 
-@pytest.mark.parametrize("B", [1, 2, 3, 4])
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 8, 16, 32, 64])
 def test_inter_corr(ops, B):
+    """the element-wise cross-modal correlation INCLUDING the batch-dependent re-view (i, b) = divmod(3 b' + i', B) of
+    mmvit4.py:481-487, forward and backward, against the CPU oracle - at the small batches of the reference fixtures and at the batches
+    BASELINE's configurations run per GPU (8 / 16 / 32 / 64)."""
     from oracle import mmvit4_oracle as O
     S, C = 512, 512
     qkvs = [rnd(B, S, 3 * C, seed=10 + i) for i in range(3)]

@@ -307,7 +307,7 @@ def test_device_oracle_is_pinned_by_the_reference_fixture():
 
 
 @pytest.mark.parametrize("name,force_single_stream", [("tame_train_b4_d4_224", False), ("oracle_train_b2_d8_256", True),
-                                                      ("oracle_train_b2_d12_512", False)])
+                                                      ("oracle_train_b2_d12_512", False), ("device_train_b8_d4_224", False)])
 def test_large_baseline_configs_fwd_bwd(name, force_single_stream, monkeypatch):
     """BASELINE configs[0] (batch 4, 4 bands, 224^2: the one configuration the reference itself runs, F4_TRAIN.py:52-61; fixture =
     the upstream reference's own fp32 run), configs[2] (8 bands, 256^2) and configs[4] (12 bands, 512^2) geometry, forward AND
@@ -319,8 +319,8 @@ def test_large_baseline_configs_fwd_bwd(name, force_single_stream, monkeypatch):
     B = 64 and configs[4] at B = 16 actually execute), forced here by patching the memory estimate.  Brackets as for the reference
     fixtures: 3x the fp32 arithmetic's own error against fp64 for the prediction, 10x (floor 1e-3) for the sampled gradients."""
     import mmvit4
-    if name in helpers.LARGE_CASES:
-        B, D, H, W, wseed = helpers.LARGE_CASES[name]
+    if name in helpers.LARGE_CASES or name in helpers.DEVICE_CASES:
+        B, D, H, W, wseed = (helpers.LARGE_CASES.get(name) or helpers.DEVICE_CASES[name])
         case = dict(B=B, D=D, H=H, W=W, mode="train_nodrop", conv_gain=1.0, wseed=wseed)
     else:
         case = CASES[name]
@@ -383,6 +383,78 @@ def test_large_baseline_configs_fwd_bwd(name, force_single_stream, monkeypatch):
     for k, b in bufs.items():
         t = r64["bufs"][k]
         assert ((b - t).norm() / t.norm()).item() < max(3 * ((r32["bufs"][k] - t).norm() / t.norm()).item(), 1e-4), k
+
+
+def test_headline_batch_taps_up_to_x6_inter():
+    """BASELINE configs[1] at ITS OWN batch (B = 32, 4 bands, 224^2; the configuration bench.py times): every stage up to x6_inter -
+    encoders (BatchNorm statistics over 32 samples), early fusion, the intra-modality transformers, the inter-modal correlation with
+    its batch-dependent re-view (mmvit4.py:481-487), the 2048-token multimodal transformer and multimodal_decode_conv - against the
+    oracle's modules evaluated on the device in fp64 (truth) and fp32 (bracket), MIOpen off.  The decoder is left out on the oracle's
+    side only because stock ATen cannot run it at this batch ("input tensor must fit into 32-bit index math" at 32 x 32 x 128^3); the
+    decoder has no cross-sample coupling and is checked at B = 8 / 4 / 2 by the cases above.  Bar per tap as for the stage taps of the
+    reference fixtures: 5 x the fp32 arithmetic's own error against fp64, floor 2e-5 of the tap's largest value."""
+    from oracle import mmvit4_oracle as O
+    import torch.nn as nn
+    case = dict(B=32, D=4, H=224, W=224, mode="train_nodrop", conv_gain=1.0, wseed=44)
+    model, sd = build_hip(case)
+    model.decoder_split = 0
+    taps = {}
+
+    def grab(store, key, conv=None):
+        def hook(mod, inp, out):
+            store[key] = (conv or sample)(out, 512)
+        return hook
+
+    names = (("e2", "RGB_encoder.e2"), ("e5", "SWIR_encoder.e5"), ("fusion3", "fusion3"), ("fusion6", "fusion6"),
+             ("NIR_transformer", "NIR_transformer"), ("qkv_RGB", "qkv_RGB"), ("qkv_SWIR", "qkv_SWIR"),
+             ("mm_transformer", "multimodal_transformer"), ("x6_inter", "multimodal_decode_conv"))
+    mods = dict(model.named_modules())
+    for key, mn in names:
+        mods[mn].register_forward_hook(grab(taps, key, _ncdhw_sample))
+    model.multimodal_transformer.register_forward_pre_hook(lambda mod, inp: taps.__setitem__("mm_in", _ncdhw_sample(inp[0], 512)))
+    x, _ = helpers.make_inputs(case["B"], case["D"], case["H"], case["W"])
+    with torch.no_grad():
+        model(x.to(DEV))
+    torch.cuda.synchronize()
+    del model
+    torch.cuda.empty_cache()
+
+    class _Stop(Exception):
+        pass
+
+    class _NoDecoder(nn.Module):
+        def forward(self, *a):
+            raise _Stop()
+
+    ref_taps = {}
+    for dt in (torch.float64, torch.float32):
+        ref = O.MMVit4()
+        ref.load_state_dict(sd)
+        ref.decoder_fuse = _NoDecoder()
+        ref = ref.to(device=DEV, dtype=dt).train()
+        O.set_dropout(ref, False)
+        store = ref_taps[dt] = {}
+        rmods = dict(ref.named_modules())
+        for key, mn in names:
+            rmods[mn].register_forward_hook(grab(store, key))
+        ref.multimodal_transformer.register_forward_pre_hook(lambda mod, inp, store=store: store.__setitem__("mm_in", sample(inp[0], 512)))
+        with torch.no_grad(), torch.backends.cudnn.flags(enabled=False):
+            try:
+                ref(x.to(device=DEV, dtype=dt))
+            except _Stop:
+                pass
+        torch.cuda.synchronize()
+        del ref
+        torch.cuda.empty_cache()
+    bad = []
+    for key in sorted(taps):
+        r64, r32 = ref_taps[torch.float64][key], ref_taps[torch.float32][key]
+        scale = max(np.abs(r64).max(), 1e-30)
+        err = np.abs(taps[key] - r64).max() / scale
+        gap = np.abs(r32 - r64).max() / scale
+        if err > max(5 * gap, 2e-5):
+            bad.append((key, err, gap))
+    assert len(taps) == 10 and not bad, bad
 
 
 def test_module_surface():
