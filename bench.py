@@ -237,8 +237,13 @@ def main():
         ops.FLASH_ATTENTION = os.environ["CORRIF_FLASH"] == "1"
     if os.environ.get("CORRIF_GROUPED") is not None:         # A/B switch: 0 = one Encoder.forward per modality (three launches per twin layer)
         model.grouped_encoders = os.environ["CORRIF_GROUPED"] == "1"
+    if os.environ.get("CORRIF_SIDE_WGRAD_G") is not None:    # A/B switch: 0 = the grouped encoder's weight gradients stay on the main stream
+        ops.SIDE_WGRAD_GROUPED = os.environ["CORRIF_SIDE_WGRAD_G"] == "1"
+    if os.environ.get("CORRIF_STREAM_K_G") is not None:      # A/B switch: 0 = no stream-K split for the grouped long-K launches
+        ops.STREAM_K_GROUPED = os.environ["CORRIF_STREAM_K_G"] == "1"
     if os.environ.get("CORRIF_SERIAL") == "1":          # profiling aid: one stream, clean per-kernel attribution
         ops.SIDE_WGRAD = False
+        ops.SIDE_WGRAD_GROUPED = False
         model.concurrent_branches = False
         model.decoder_fuse.concurrent_skips = False
         model.decoder_split = 0
@@ -281,6 +286,7 @@ def main():
         # spans the other streams' kernels, so per-kernel durations are only meaningful one stream at a time)
         model.concurrent_branches = False
         side_was, ops.SIDE_WGRAD = ops.SIDE_WGRAD, False
+        sideg_was, ops.SIDE_WGRAD_GROUPED = ops.SIDE_WGRAD_GROUPED, False
         split_was, model.decoder_split = model.decoder_split, 0
         skips_was, model.decoder_fuse.concurrent_skips = model.decoder_fuse.concurrent_skips, False
         kt_steps = min(2, args.steps)
@@ -299,6 +305,7 @@ def main():
         del ga, gb, gc
         model.concurrent_branches = True
         ops.SIDE_WGRAD = side_was
+        ops.SIDE_WGRAD_GROUPED = sideg_was
         model.decoder_split = split_was
         model.decoder_fuse.concurrent_skips = skips_was
     if world > 1:

@@ -67,66 +67,87 @@ extern "C" int corrif_add_bcast_rows(const float* a, const float* b, int64_t b_n
     return CORRIF_OK;
 }
 // ------------------------------------------------------------------ depth-class broadcast (decoder skip branch on a compact depth grid)
-// A tensor that is the nearest-neighbour up-sampling of Ds depth slices to D = f * Ds slices is constant along depth inside each block
-// of f slices, so a 3x3x3 convolution of it (replicate padded) takes only three distinct values per block: at the block's first slice,
-// at its last slice and everywhere in between.  The decoder therefore evaluates the skip branch's share of d*_c2 on a grid of 3 * Ds
-// slices (class c = 3 k + {0 first, 1 interior, 2 last} of block k) and these two kernels broadcast it into / reduce it out of the
-// full-depth tensor:   y[b, d, s, :] += ys[b, cls(d), s, :]        g_ys[b, c, s, :] = sum over d with cls(d) = c of g[b, d, s, :]
-__device__ __forceinline__ int depth_class(int d, int f, FastDiv df) {
-    const int k = (int)fdiv((uint32_t)d, df), r = d - k * f;
-    return 3 * k + (r == 0 ? 0 : (r == f - 1 ? 2 : 1));
+// A tensor that is the nearest-neighbour up-sampling of Ds depth slices to D slices (F.interpolate(nearest): source slice of d is
+// min(floor(d * Ds / D), Ds - 1) in float arithmetic, mmvit4.py:271-286) is constant along depth inside each BLOCK of consecutive slices
+// that share a source - D / Ds slices when Ds divides D, floor or ceil of it otherwise (the reference-native 3 bands, 12 bands) - so a
+// 3x3x3 convolution of it (replicate padded) takes only three distinct values per block: at the block's first slice, at its last slice
+// and everywhere in between (blocks are at least two slices long: D >= 2 Ds).  The decoder therefore evaluates the skip branch's share
+// of d*_c2 on a grid of 3 * Ds slices (class c = 3 k + {0 first, 1 interior, 2 last} of block k) and these two kernels broadcast it
+// into / reduce it out of the full-depth tensor:
+//     y[b, d, s, :] += ys[b, cls(d), s, :]        g_ys[b, c, s, :] = sum over d with cls(d) = c of g[b, d, s, :]
+struct DAxis { int in, out; float scale; };      // the depth axis of nearest_fwd_kernel (same float arithmetic)
+static DAxis make_daxis(int in, int out) { DAxis a; a.in = in; a.out = out; a.scale = (float)in / (float)out; return a; }
+__device__ __forceinline__ int depth_src(const DAxis& a, int o) {
+    int s = (int)floorf((float)o * a.scale);
+    return s < a.in - 1 ? s : a.in - 1;
 }
-__global__ void depth_bcast_add_kernel(float* __restrict__ y, int64_t ldy, const float* __restrict__ ys, int64_t lds, int64_t total, int D,
-                                       int f, int C4, FastDiv dC, FastDiv dS, FastDiv dD, FastDiv df, int S) {
+__device__ __forceinline__ int depth_class(int d, const DAxis& a) {
+    const int k = depth_src(a, d);
+    const bool first = d == 0 || depth_src(a, d - 1) != k, last = d == a.out - 1 || depth_src(a, d + 1) != k;
+    return 3 * k + (first ? 0 : (last ? 2 : 1));
+}
+// first / last slice of block k (the slices whose source is k)
+__device__ __forceinline__ void depth_block(const DAxis& a, int k, int& lo, int& hi) {
+    const float inv = 1.0f / a.scale;
+    lo = (int)floorf((float)k * inv) - 1;
+    hi = (int)ceilf((float)(k + 1) * inv) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > a.out - 1) hi = a.out - 1;
+    while (lo <= hi && depth_src(a, lo) != k) ++lo;
+    while (hi >= lo && depth_src(a, hi) != k) --hi;
+}
+__global__ void depth_bcast_add_kernel(float* __restrict__ y, int64_t ldy, const float* __restrict__ ys, int64_t lds, int64_t total, DAxis ad,
+                                       int C4, FastDiv dC, FastDiv dS, FastDiv dD, int S) {
     GRID_STRIDE(i, total) {        // i = ((b * D + d) * S + s) * C4 + c
         uint32_t t = (uint32_t)i;
         const uint32_t row = fdiv(t, dC), c = t - row * dC.d;
         const uint32_t bd = fdiv(row, dS), sp = row - bd * dS.d;
         const uint32_t b = fdiv(bd, dD), d = bd - b * dD.d;
-        const int64_t srow = ((int64_t)b * (3 * (D / f)) + depth_class((int)d, f, df)) * S + sp;
+        const int64_t srow = ((int64_t)b * (3 * ad.in) + depth_class((int)d, ad)) * S + sp;
         f32x4 v = *reinterpret_cast<const f32x4*>(y + (int64_t)row * ldy + c * 4);
         v += *reinterpret_cast<const f32x4*>(ys + srow * lds + c * 4);
         *reinterpret_cast<f32x4*>(y + (int64_t)row * ldy + c * 4) = v;
     }
 }
-__global__ void depth_class_reduce_kernel(const float* __restrict__ g, int64_t ldg, float* __restrict__ out, int64_t ldo, int64_t total, int D,
-                                          int f, int C4, FastDiv dC, FastDiv dS, FastDiv dK, int S) {
-    GRID_STRIDE(i, total) {        // i = ((b * Ds + k) * S + s) * C4 + c ; fixed summation order d = k f + 1 .. k f + f - 2
+__global__ void depth_class_reduce_kernel(const float* __restrict__ g, int64_t ldg, float* __restrict__ out, int64_t ldo, int64_t total, DAxis ad,
+                                          int C4, FastDiv dC, FastDiv dS, FastDiv dK, int S) {
+    GRID_STRIDE(i, total) {        // i = ((b * Ds + k) * S + s) * C4 + c ; fixed summation order over the interior slices of block k
         uint32_t t = (uint32_t)i;
         const uint32_t row = fdiv(t, dC), c = t - row * dC.d;
         const uint32_t bk = fdiv(row, dS), sp = row - bk * dS.d;
         const uint32_t b = fdiv(bk, dK), k = bk - b * dK.d;
-        const float* __restrict__ src = g + (((int64_t)b * D + (int64_t)k * f) * S + sp) * ldg + c * 4;
+        int lo, hi;
+        depth_block(ad, (int)k, lo, hi);
+        const float* __restrict__ src = g + (((int64_t)b * ad.out) * S + sp) * ldg + c * 4;
         const int64_t step = (int64_t)S * ldg;
         float* __restrict__ dst = out + (((int64_t)b * 3 * dK.d + 3 * k) * S + sp) * ldo + c * 4;
-        *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(src);
+        *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(src + lo * step);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int r = 1; r < f - 1; ++r) acc += *reinterpret_cast<const f32x4*>(src + r * step);
+        for (int r = lo + 1; r < hi; ++r) acc += *reinterpret_cast<const f32x4*>(src + r * step);
         *reinterpret_cast<f32x4*>(dst + (int64_t)S * ldo) = acc;
-        *reinterpret_cast<f32x4*>(dst + 2 * (int64_t)S * ldo) = *reinterpret_cast<const f32x4*>(src + (int64_t)(f - 1) * step);
+        *reinterpret_cast<f32x4*>(dst + 2 * (int64_t)S * ldo) = *reinterpret_cast<const f32x4*>(src + (int64_t)hi * step);
     }
 }
-static bool depth_args_ok(const void* a, int64_t lda, const void* b, int64_t ldb, int32_t B, int32_t D, int32_t S, int32_t C, int32_t f) {
-    if (!a || !b || B <= 0 || D <= 0 || S <= 0 || C <= 0 || f < 2 || (D % f)) return false;
+static bool depth_args_ok(const void* a, int64_t lda, const void* b, int64_t ldb, int32_t B, int32_t D, int32_t S, int32_t C, int32_t Ds) {
+    if (!a || !b || B <= 0 || D <= 0 || S <= 0 || C <= 0 || Ds < 1 || D < 2 * Ds) return false;      // every block has a first and a last slice
     if ((C & 3) || (lda & 3) || (ldb & 3) || lda < C || ldb < C || !al16(a) || !al16(b)) return false;
     return (int64_t)B * D * S * (C / 4) < ((int64_t)1 << 31);
 }
-extern "C" int corrif_depth_bcast_add(float* y, int64_t ldy, const float* ys, int64_t lds, int32_t B, int32_t D, int32_t S, int32_t C, int32_t f,
+extern "C" int corrif_depth_bcast_add(float* y, int64_t ldy, const float* ys, int64_t lds, int32_t B, int32_t D, int32_t S, int32_t C, int32_t Ds,
                                       void* stream) {
-    if (!depth_args_ok(y, ldy, ys, lds, B, D, S, C, f)) return CORRIF_EINVAL;
+    if (!depth_args_ok(y, ldy, ys, lds, B, D, S, C, Ds)) return CORRIF_EINVAL;
     const int64_t total = (int64_t)B * D * S * (C / 4);
-    hipLaunchKernelGGL(depth_bcast_add_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, y, ldy, ys, lds, total, (int)D, (int)f,
-                       C / 4, make_fastdiv((uint32_t)(C / 4)), make_fastdiv((uint32_t)S), make_fastdiv((uint32_t)D), make_fastdiv((uint32_t)f), (int)S);
+    hipLaunchKernelGGL(depth_bcast_add_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, y, ldy, ys, lds, total, make_daxis(Ds, D),
+                       C / 4, make_fastdiv((uint32_t)(C / 4)), make_fastdiv((uint32_t)S), make_fastdiv((uint32_t)D), (int)S);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
-extern "C" int corrif_depth_class_reduce(const float* g, int64_t ldg, float* out, int64_t ldo, int32_t B, int32_t D, int32_t S, int32_t C, int32_t f,
+extern "C" int corrif_depth_class_reduce(const float* g, int64_t ldg, float* out, int64_t ldo, int32_t B, int32_t D, int32_t S, int32_t C, int32_t Ds,
                                          void* stream) {
-    if (!depth_args_ok(g, ldg, out, ldo, B, D, S, C, f)) return CORRIF_EINVAL;
-    const int Ds = D / f;
+    if (!depth_args_ok(g, ldg, out, ldo, B, D, S, C, Ds)) return CORRIF_EINVAL;
     const int64_t total = (int64_t)B * Ds * S * (C / 4);
-    hipLaunchKernelGGL(depth_class_reduce_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, g, ldg, out, ldo, total, (int)D, (int)f,
-                       C / 4, make_fastdiv((uint32_t)(C / 4)), make_fastdiv((uint32_t)S), make_fastdiv((uint32_t)Ds), (int)S);
+    hipLaunchKernelGGL(depth_class_reduce_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, g, ldg, out, ldo, total,
+                       make_daxis(Ds, D), C / 4, make_fastdiv((uint32_t)(C / 4)), make_fastdiv((uint32_t)S), make_fastdiv((uint32_t)Ds), (int)S);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }

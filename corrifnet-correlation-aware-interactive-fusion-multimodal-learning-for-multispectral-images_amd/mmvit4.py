@@ -32,7 +32,7 @@ depth = 1
 num_modals = 3
 patch_size = 8
 _MODS = ("RGB", "NIR", "SWIR")
-CAPTURE_LANES = False # diagnostics: True lets a HIP-graph capture keep the sample-group lanes (see _run_lanes)
+CAPTURE_LANES = True  # diagnostics: False leaves the sample-group lanes out of HIP-graph captures (round 2 behaviour, see _run_lanes)
 GRAD_TAP = True       # Bottleneck identity blocks: fold the residual gradient into conv1's data-gradient epilogue (ops.grad_tap)
 
 
@@ -437,6 +437,7 @@ class Decoder_fuse(nn.Module):
         self.compact_skips = True       # diagnostics / A-B: False materialises the up-sampled skip tensors and the concat buffers
         self._side = None
         self._edges = {}
+        self._fork_from = {}            # lane -> event on the stream the lanes forked from (set by _run_lanes, see forward)
 
     def forward(self, x1, x2, x3, x4, x5, lane=0):
         B, dev = x5.shape[0], x5.device
@@ -444,9 +445,10 @@ class Decoder_fuse(nn.Module):
                   (self.RFM3, x3, 32, self.d3_c1, self.d3_c2, self.d3_out),
                   (self.RFM2, x2, 64, self.d2_c1, self.d2_c2, self.d2_out),
                   (self.RFM1, x1, 128, self.d1_c1, self.d1_c2, self.d1_out))
-        # Compact skip branch.  F.interpolate(nearest) of the RFM output from Ds to n = f * Ds depth slices (mmvit4.py:271-286) is
-        # constant along depth inside each block of f slices, so its share of the replicate-padded 3x3x3 convolution d*_c2 takes three
-        # distinct values per block (first slice / interior / last slice).  For f >= 8 that share is evaluated on a grid of 3 * Ds slices
+        # Compact skip branch.  F.interpolate(nearest) of the RFM output from Ds to n depth slices (mmvit4.py:271-286) is constant
+        # along depth inside each block of slices that share a source (n / Ds slices, or floor / ceil of it when Ds does not divide n:
+        # the reference-native 3 bands, 12 bands), so its share of the replicate-padded 3x3x3 convolution d*_c2 takes three
+        # distinct values per block (first slice / interior / last slice).  For n / Ds >= 8 that share is evaluated on a grid of 3 * Ds slices
         # - nearest-up-sampling to (3 Ds, n, n), the same convolution with the weight's skip channels, no bias - and broadcast into the
         # convolution of the other (d*_c1) channels: d1_c2 at 4 bands runs 8 + 24 * 12/128 instead of 32 input channels' worth of
         # forward, data-gradient and weight-gradient work, the 128^3 x 24-channel up-sampled tensor and the concat buffer disappear.
@@ -454,7 +456,7 @@ class Decoder_fuse(nn.Module):
         fs = []
         for _, skip, n, _, _, _ in stages:
             Ds = skip.shape[1]
-            fs.append(n // Ds if (self.compact_skips and n % Ds == 0 and n // Ds >= 8) else 0)
+            fs.append(n // Ds if (self.compact_skips and n // Ds >= 8) else 0)       # any ratio: blocks of floor / ceil(n / Ds) slices
         cats = [None if fs[l] else torch.empty((B, n, n, n, skip.shape[-1] + c1.conv.weight.shape[0]), dtype=torch.float32, device=dev)
                 for l, (_, skip, n, c1, _, _) in enumerate(stages)]
 
@@ -481,8 +483,27 @@ class Decoder_fuse(nn.Module):
                 side = self._side[lane] = torch.cuda.Stream(device=dev)
             edges = self._edges.setdefault(lane, _Edges())
             edges.reset()
-            edges.edge(cur, side)
-            for t in (x1, x2, x3, x4) + tuple(c for c in cats if c is not None):      # allocated on the caller's stream, used (and saved) on the side stream
+            # Inside a sample-group lane the skip stream forks from the event the LANES forked from (recorded by _run_lanes on its
+            # caller's stream), never from its own lane's stream: hipStreamEndCapture of ROCm 7.2 segfaults as soon as a stream of a
+            # capture waits for an event that a FORKED stream recorded and later joins that stream again (fork -> fork -> join -> join;
+            # tools/probe/graph_fork2.py: `raw` / `join1` / `onelane` / `origin_lane` crash with torch streams, events and element-wise
+            # kernels alone - the round-2 crash "at batch >= 2" was this, no product code involved - while `origin`, the topology used
+            # here, captures and replays).  The branch's inputs are all older than that event, so nothing is lost; the concat buffers
+            # it writes are then allocated on ITS stream (their previous use, if any, was its own), see below.
+            fork = self._fork_from.pop(lane, None)
+            if fork is not None:
+                side.wait_event(fork)
+                with torch.cuda.stream(side):
+                    cats = [None if c is None else torch.empty_like(c) for c in cats]
+                for c in cats:
+                    if c is not None:
+                        _rs(c, cur)
+            else:
+                edges.edge(cur, side)
+                for c in cats:
+                    if c is not None:
+                        _rs(c, side)          # allocated on the caller's stream, written (and saved) on the side stream
+            for t in (x1, x2, x3, x4):
                 _rs(t, side)
             events = []
             with torch.cuda.stream(side):
@@ -506,7 +527,7 @@ class Decoder_fuse(nn.Module):
             if fs[l]:
                 ys, w_y = parts_s[l]
                 yc = ops.conv3d(part_y, w_y, c2.conv.bias, c2.conv.stride, c2.conv.pad, c2.conv.replicate)
-                y = cout(c2.norm(ops.depth_bcast_add(yc, ys, fs[l])))
+                y = cout(c2.norm(ops.depth_bcast_add(yc, ys)))
             else:
                 y = cout(c2(ops.cat_channels(cat, parts_s[l], part_y)))
         up = ops.trilinear(y, (1, 224, 224))                                   # up_to_224 (mmvit4.py:263): depth slice 0 only
@@ -869,11 +890,7 @@ def _run_lanes(model, tail, shared, *per_sample):
     B = per_sample[0].shape[0]
     lanes = min(int(model.decoder_split), B) if model.decoder_split else 1
     if lanes >= 2 and torch.cuda.is_current_stream_capturing() and not CAPTURE_LANES:
-        # Not inside a HIP-graph capture: a captured forward with two lanes (a second fork level: capture stream -> lane stream ->
-        # the decoder's skip stream) crashes the HIP runtime of ROCm 7.2 at batch >= 2 (tools/probe/graph_cases.py case C; one lane,
-        # two captures on one model, batch 4 without lanes all work).  Not diagnosed; the captured schedule keeps the three branch
-        # streams and the skip stream.
-        lanes = 1
+        lanes = 1          # diagnostics switch only (round 2 kept the lanes out of captures; the cause and the fix are in Decoder_fuse.forward)
     if lanes < 2:
         return tail(*per_sample)
     cur = torch.cuda.current_stream()
@@ -882,9 +899,13 @@ def _run_lanes(model, tail, shared, *per_sample):
     bounds = [B * k // lanes for k in range(lanes + 1)]
     ins = [ops.split_batch(t, bounds) for t in per_sample]
     outs = []
+    fork = model._edges.mark(cur)            # the lanes AND their decoder skip streams fork from here (one fork level, see Decoder_fuse.forward)
+    dec = getattr(model, "decoder_fuse", None)
     for k in range(lanes):
         st = model._dec_streams[k]
-        model._edges.edge(cur, st)
+        st.wait_event(fork)
+        if dec is not None and dec.concurrent_skips:
+            dec._fork_from[k] = fork
         _rs(shared, st)
         for t in ins:
             _rs(t[k], st)

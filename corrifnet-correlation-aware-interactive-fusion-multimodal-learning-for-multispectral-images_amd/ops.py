@@ -63,6 +63,9 @@ STREAM_K = False
 # STREAM_K_LONG restricts it to where it helps a launch in isolation: long K loops on a small tile grid (e4 / e5's 3x3 convolutions and
 # their data gradients: 392 / 196 tiles of 128 x 128 on 512 slots, 72 / 144 K tiles; 84 -> 98 TFLOP/s alone, tools/gemm_lab.hip).
 STREAM_K_LONG = False     # measured (round 2): wall-neutral on the B=32 step (248.4 vs 248.0 ms), the branch streams already fill those tails
+# Grouped launches (Z = 3 twin layers of the modality encoders) with a long K loop: the split pays (tools/group_microbench.py, round 3: e4 conv2
+# 99 -> 106 TFLOP/s, e5 conv2 85 -> 108, e5 conv1 92 -> 102) while short-K shapes lose 8-9 % to the slab round trip (K <= 1024).
+STREAM_K_GROUPED = True
 
 
 def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, addend=None, ld_add=0, act=ACT_NONE,
@@ -97,7 +100,7 @@ def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, add
     g.sC_o, g.sC_i = sC
     g.g = geom
     buf = None
-    sk = STREAM_K or (STREAM_K_LONG and K >= 2048 and Z == 1 and M * N <= 128 * 128 * 512)
+    sk = STREAM_K or (STREAM_K_LONG and K >= 2048 and Z == 1 and M * N <= 128 * 128 * 512) or (STREAM_K_GROUPED and zs is not None and K >= 2048)
     g.no_split = 0 if sk else 1
     if sk:
         nws = lib().corrif_gemm_fwd_workspace(g)      # stream-K split: slabs for the tiles a share boundary cuts
@@ -290,6 +293,7 @@ class _NullCtx:
 # callback at the end of the backward pass.  Measured (round 2, one box, alternating runs): 251.1 ms per step with it, 250.7 without -
 # the normalisation passes and the weight gradients share the CUs either way - so it is OFF; kept as a switch.
 SIDE_WGRAD = False
+SIDE_WGRAD_GROUPED = True      # the grouped (stacked-modality) encoder: see GroupedConvFn.backward
 _side_streams = {}            # id of the stream a backward node runs on -> (side stream, event pool, cursor)
 _side_pending = {"queued": False}
 
@@ -578,32 +582,34 @@ def split_weight(w, cs):
 
 
 class DepthBcastAddFn(Function):
-    """y[b, d] += ys[b, cls(d)] in place (corrif_depth_bcast_add): `ys` lives on the compact depth grid of 3 * (D / f) slices, see
-    Decoder_fuse.forward.  Backward: the gradient passes through to y and is class-reduced for ys."""
+    """y[b, d] += ys[b, cls(d)] in place (corrif_depth_bcast_add): `ys` lives on the compact depth grid of 3 * Ds slices (three depth
+    classes per block of slices that share a nearest-neighbour source), see Decoder_fuse.forward.  Backward: the gradient passes
+    through to y and is class-reduced for ys."""
 
     @staticmethod
-    def forward(ctx, y, ys, f):
+    def forward(ctx, y, ys):
         B, D, Hh, W, C = y.shape
         yv, _, ldy = rows_view(y)
         sv, _, lds = rows_view(ys)
-        assert yv is y and tuple(ys.shape) == (B, 3 * (D // f), Hh, W, C) and D % f == 0
-        check(lib().corrif_depth_bcast_add(P(y), ldy, P(sv), lds, B, D, Hh * W, C, f, stream()), "corrif_depth_bcast_add")
+        Ds = ys.shape[1] // 3
+        assert yv is y and tuple(ys.shape) == (B, 3 * Ds, Hh, W, C) and D >= 2 * Ds
+        check(lib().corrif_depth_bcast_add(P(y), ldy, P(sv), lds, B, D, Hh * W, C, Ds, stream()), "corrif_depth_bcast_add")
         ctx.mark_dirty(y)
-        ctx.cfg = (f, tuple(ys.shape))
+        ctx.cfg = (Ds, tuple(ys.shape))
         return y
 
     @staticmethod
     def backward(ctx, g):
-        f, sshape = ctx.cfg
+        Ds, sshape = ctx.cfg
         B, D, Hh, W, C = g.shape
         gv, _, ldg = rows_view(g)
         gs = torch.empty(sshape, dtype=torch.float32, device=g.device)
-        check(lib().corrif_depth_class_reduce(P(gv), ldg, P(gs), C, B, D, Hh * W, C, f, stream()), "corrif_depth_class_reduce")
-        return g, gs, None
+        check(lib().corrif_depth_class_reduce(P(gv), ldg, P(gs), C, B, D, Hh * W, C, Ds, stream()), "corrif_depth_class_reduce")
+        return g, gs
 
 
-def depth_bcast_add(y, ys, f):
-    return DepthBcastAddFn.apply(y, ys, f)
+def depth_bcast_add(y, ys):
+    return DepthBcastAddFn.apply(y, ys)
 
 
 # --------------------------------------------------------------------------------------- grouped (stacked-modality) operators
@@ -647,7 +653,8 @@ class GroupedConvFn(Function):
     (1,2,2), pad (0,1,1)), zero padding, Ci > 1."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, G, zin, zout, out, stats_req, grad_link, bwd_stats):
+    def forward(ctx, x, w, b, stride, pad, G, zin, zout, out, stats_req, grad_link, bwd_stats, side_ok=False):
+        ctx.side_ok = side_ok
         _, Co, Ci, kd, kh, kw = w.shape
         T = kd * kh * kw
         x, _, lda = rows_view(x)
@@ -729,26 +736,32 @@ class GroupedConvFn(Function):
                     st, bst, zs = _bwd_stats_request_g(ctx.bwd_stats, ctx.grad_link, Min, Ci, G, dev, x, lda)
                     gemm(P(gy), ldg, P(wd), Ci, 1, P(gx), Ci, Min, Ci, T * Co, Co, geom, stats=st, bstats=bst,
                          Z=G, sA=(zG, 0), sB=(T * Co * Ci, 0), sC=(zX, 0), zs=zs)
-        if ctx.needs_input_grad[1]:
-            gw = torch.empty(w.shape, dtype=torch.float32, device=dev)
-            if T == 1:
-                geom = H.gemm_geom() if is_gemm else H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (1, 1, 1), stride, pad)
-                wgrad(P(gy), ldg, P(x), lda, Ci, P(gw), Ci, M, Co, Ci, geom, dev, Z=G, sA=(zG, 0), sB=(zA, 0), sC=(Co * Ci, 0))
-            else:
-                gwp = torch.empty((G, Co, T * Ci), dtype=torch.float32, device=dev)
-                geom = H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad)
-                wgrad(P(gy), ldg, P(x), lda, Ci, P(gwp), T * Ci, M, Co, T * Ci, geom, dev, Z=G, sA=(zG, 0), sB=(zA, 0), sC=(Co * T * Ci, 0))
-                check(lib().corrif_weight_repack(P(gwp), P(gw), G * Co, Ci, T, 2, T * Ci, stream()), "corrif_weight_repack")
-        if has_bias and ctx.needs_input_grad[2]:
-            gb = torch.empty((G, Co), dtype=torch.float32, device=dev)
-            if zout == "stack":
-                ws = _ws(lib().corrif_norm_workspace(M, G, Co), dev)
-                check(lib().corrif_col_sum_g(P(gy), ldg, M, G, Co, P(gb), P(ws), stream()), "corrif_col_sum_g")
-            else:                                     # concat layout: the column sums of the [M][G*Co] gradient ARE [G][Co]
-                ws = _ws(lib().corrif_col_sum_workspace(M, G * Co), dev)
-                check(lib().corrif_col_sum(P(gy), ldg, M, G * Co, P(gb), P(ws), stream()), "corrif_col_sum")
+        # weight / bias gradients are off the backward's critical path: on a side stream they keep the matrix pipe busy under the HBM-bound
+        # BatchNorm backward passes that follow on the main stream (the grouped encoder has no sibling branch streams to fill them)
+        side = None
+        if SIDE_WGRAD_GROUPED and ctx.side_ok and ctx.needs_input_grad[1] and not torch.cuda.is_current_stream_capturing():
+            side = _side_begin((gy, x, w))
+        with torch.cuda.stream(side) if side is not None else _NullCtx():
+            if ctx.needs_input_grad[1]:
+                gw = torch.empty(w.shape, dtype=torch.float32, device=dev)
+                if T == 1:
+                    geom = H.gemm_geom() if is_gemm else H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (1, 1, 1), stride, pad)
+                    wgrad(P(gy), ldg, P(x), lda, Ci, P(gw), Ci, M, Co, Ci, geom, dev, Z=G, sA=(zG, 0), sB=(zA, 0), sC=(Co * Ci, 0))
+                else:
+                    gwp = torch.empty((G, Co, T * Ci), dtype=torch.float32, device=dev)
+                    geom = H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad)
+                    wgrad(P(gy), ldg, P(x), lda, Ci, P(gwp), T * Ci, M, Co, T * Ci, geom, dev, Z=G, sA=(zG, 0), sB=(zA, 0), sC=(Co * T * Ci, 0))
+                    check(lib().corrif_weight_repack(P(gwp), P(gw), G * Co, Ci, T, 2, T * Ci, stream()), "corrif_weight_repack")
+            if has_bias and ctx.needs_input_grad[2]:
+                gb = torch.empty((G, Co), dtype=torch.float32, device=dev)
+                if zout == "stack":
+                    ws = _ws(lib().corrif_norm_workspace(M, G, Co), dev)
+                    check(lib().corrif_col_sum_g(P(gy), ldg, M, G, Co, P(gb), P(ws), stream()), "corrif_col_sum_g")
+                else:                                     # concat layout: the column sums of the [M][G*Co] gradient ARE [G][Co]
+                    ws = _ws(lib().corrif_col_sum_workspace(M, G * Co), dev)
+                    check(lib().corrif_col_sum(P(gy), ldg, M, G * Co, P(gb), P(ws), stream()), "corrif_col_sum")
         gx = _finish_link(ctx.grad_link, gx)
-        return gx, gw, gb, None, None, None, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None, None, None
 
 
 def _bwd_stats_request_g(bl, grad_link, rows, C, G, dev, xin, ldin):
@@ -769,7 +782,9 @@ def conv3d_grouped(x, weights, biases, stride, pad, zin="stack", zout="stack", o
     G = len(weights)
     w = stack_params(weights)
     b = stack_params(biases) if biases[0] is not None else None
-    return GroupedConvFn.apply(x, w, b, tuple(stride), tuple(pad), G, zin, zout, out, stats, grad_link, bwd_stats)
+    # the side-stream weight gradient is only safe when autograd will ADOPT the produced gradients (no accumulation kernel on another stream)
+    side_ok = all(t.grad is None for t in weights) and all(t is None or t.grad is None for t in biases)
+    return GroupedConvFn.apply(x, w, b, tuple(stride), tuple(pad), G, zin, zout, out, stats, grad_link, bwd_stats, side_ok)
 
 
 class GroupedBatchNormFn(Function):

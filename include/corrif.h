@@ -341,14 +341,15 @@ int corrif_flash_attn_bwd(const float* qkv, const float* out, const float* lse, 
 int corrif_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 
 /* Depth-class broadcast for the decoder's skip branch (mmvit4.py:271-287: F.interpolate(nearest) -> cat -> d*_c2).  The nearest
- * up-sampling of Ds depth slices to D = f*Ds is constant along depth inside each block of f slices, so a replicate-padded 3x3x3
- * convolution of it takes three distinct values per block (first slice / interior / last slice).  The host evaluates that share of
- * the convolution on a compact grid of 3*Ds slices (class 3k + {0,1,2} of block k) and these two calls move it in and out of the
- * full-depth tensor (channels-last, S = H*W voxels per slice, row pitches ld*):
+ * up-sampling of Ds depth slices to D >= 2*Ds slices (source of slice d = min(floor(d*Ds/D), Ds-1), ATen's float arithmetic; D need
+ * not be a multiple of Ds since ABI 6: the reference-native 3 bands, 12 bands) is constant along depth inside each block of slices that
+ * share a source, so a replicate-padded 3x3x3 convolution of it takes three distinct values per block (first slice / interior / last
+ * slice).  The host evaluates that share of the convolution on a compact grid of 3*Ds slices (class 3k + {0,1,2} of block k) and these
+ * two calls move it in and out of the full-depth tensor (channels-last, S = H*W voxels per slice, row pitches ld*):
  *   corrif_depth_bcast_add:    y[b,d,s,:] += ys[b, cls(d), s, :]                     (in place on the convolution of the other channels)
  *   corrif_depth_class_reduce: out[b,c,s,:] = sum over d with cls(d) = c of g[b,d,s,:]   (its adjoint; fixed summation order) */
-int corrif_depth_bcast_add(float* y, int64_t ldy, const float* ys, int64_t lds, int32_t B, int32_t D, int32_t S, int32_t C, int32_t f, void* stream);
-int corrif_depth_class_reduce(const float* g, int64_t ldg, float* out, int64_t ldo, int32_t B, int32_t D, int32_t S, int32_t C, int32_t f, void* stream);
+int corrif_depth_bcast_add(float* y, int64_t ldy, const float* ys, int64_t lds, int32_t B, int32_t D, int32_t S, int32_t C, int32_t Ds, void* stream);
+int corrif_depth_class_reduce(const float* g, int64_t ldg, float* out, int64_t ldo, int32_t B, int32_t D, int32_t S, int32_t C, int32_t Ds, void* stream);
 
 /* element-wise helpers (aten::add / gelu_backward / mul): y = a + b ; dx = dy * gelu'(x) */
 int corrif_add(const float* a, const float* b, float* y, int64_t n, void* stream);

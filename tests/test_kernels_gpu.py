@@ -510,31 +510,35 @@ def test_nearest(ops, src, dst):
     assert rel(ncdhw(xg.grad), xr.grad) < 2e-6
 
 
-@pytest.mark.parametrize("f", [8, 32])
-def test_depth_class_broadcast_and_reduce(ops, f):
-    """y[b,d] += ys[b, cls(d)] and its adjoint (class 3k + {0 first, 1 interior, 2 last} of up-sampling block k); and the identity the
-    decoder relies on: a replicate-padded 3x3x3 conv of a depth-nearest-up-sampled tensor equals the broadcast of the same conv on the
-    compact 3-slices-per-block grid."""
-    B, Ds, Hh, W, C = 2, 3, 5, 8, 8
-    D = f * Ds
-    cls = torch.tensor([3 * (d // f) + (0 if d % f == 0 else 2 if d % f == f - 1 else 1) for d in range(D)])
+@pytest.mark.parametrize("Ds,D", [(3, 24), (3, 96), (3, 32), (12, 128), (5, 64), (4, 9)],
+                         ids=["f8", "f32", "3_to_32_ragged", "12_to_128_ragged", "5_to_64_ragged", "4_to_9_blocks_of_2_3"])
+def test_depth_class_broadcast_and_reduce(ops, Ds, D):
+    """y[b,d] += ys[b, cls(d)] and its adjoint (class 3k + {0 first, 1 interior, 2 last} of up-sampling block k = the slices whose
+    nearest-neighbour source is k), for depth ratios that divide (4 / 8 bands) and that do not (the reference-native 3 bands, 12 bands:
+    blocks of floor / ceil(D / Ds) slices); and the identity the decoder relies on: a replicate-padded 3x3x3 conv of a
+    depth-nearest-up-sampled tensor equals the broadcast of the same conv on the compact 3-slices-per-block grid.  The block structure
+    is taken from F.interpolate itself."""
+    B, Hh, W, C = 2, 5, 8, 8
+    src = F.interpolate(torch.arange(Ds, dtype=torch.float32).view(1, 1, Ds, 1, 1), size=(D, 1, 1), mode="nearest").view(-1).long()
+    cls = torch.tensor([3 * int(src[d]) + (0 if d == 0 or src[d - 1] != src[d] else 2 if d == D - 1 or src[d + 1] != src[d] else 1)
+                        for d in range(D)])
     y = rnd(B, D, Hh, W, C, seed=1)
     ys = rnd(B, 3 * Ds, Hh, W, C, seed=2)
     yg = y.clone().to(DEV).requires_grad_()
     sg = ys.clone().to(DEV).requires_grad_()
-    out = ops.depth_bcast_add(yg * 1.0, sg, f)
+    out = ops.depth_bcast_add(yg * 1.0, sg)
     go = rnd(B, D, Hh, W, C, seed=3)
     out.backward(go.to(DEV))
     torch.cuda.synchronize()
     assert torch.equal(out.detach().cpu(), y + ys[:, cls])
     gs_ref = torch.zeros_like(ys).index_add_(1, cls, go)
     assert torch.equal(yg.grad.cpu(), go) and rel(sg.grad, gs_ref) < 1e-6
-    # the convolution identity, on the CPU with stock ops
+    # the convolution identity, on the CPU with stock ops (F.interpolate is what the reference calls at mmvit4.py:271-286)
     x = rnd(1, 4, Ds, 6, 6, seed=4)
     w = rnd(5, 4, 3, 3, 3, seed=5)
     conv = lambda t: F.conv3d(F.pad(t, (1, 1, 1, 1, 1, 1), mode="replicate"), w)
-    full = conv(x.repeat_interleave(f, dim=2))
-    compact = conv(x.repeat_interleave(3, dim=2))
+    full = conv(F.interpolate(x, size=(D, 6, 6), mode="nearest"))
+    compact = conv(F.interpolate(x, size=(3 * Ds, 6, 6), mode="nearest"))
     assert (full - compact[:, :, cls]).abs().max().item() < 1e-5
 
 

@@ -259,7 +259,7 @@ def test_other_baseline_configs_forward(B, D, HW):
     assert (pg.cpu() - pr).abs().max().item() < 1.5e-4
 
 
-def _oracle_on_device(case, dtype, sd, device=DEV):
+def _oracle_on_device(case, dtype, sd, device=DEV, all_grads=False):
     """The oracle's module tree (stock torch ops, oracle/mmvit4_oracle.py) evaluated ON THE GPU BOX'S DEVICE in `dtype`: forward +
     loss + backward in train-nodrop mode.  Used as the checker where the CPU would need hours (12 bands 512^2: the fp64 CPU run of
     the 8-band case alone takes > 20 min on the box's host share).  test_device_oracle_is_pinned_by_the_reference_fixture ties this
@@ -279,7 +279,7 @@ def _oracle_on_device(case, dtype, sd, device=DEV):
         loss.backward()
     torch.cuda.synchronize()
     out = {"pred_sample": pred.detach()[:, :, 0, ::4, ::4].double().cpu().numpy(), "loss": loss.item(),
-           "grads": {k: p.grad.double() for k, p in ref.named_parameters() if k in helpers.GRAD_KEYS},
+           "grads": {k: p.grad.double() for k, p in ref.named_parameters() if p.grad is not None and (all_grads or k in helpers.GRAD_KEYS)},
            "bufs": {k: ref.state_dict()[k].double().cpu() for k in ("RGB_encoder.e1_bn.running_mean", "SWIR_encoder.e5.2.bn3.running_var")}}
     n = case["B"] * 224 * 224
     out["jaccard2"] = helpers.jaccard2_ref(mask[:, 0].reshape(n, 1), pred.detach()[:, 0].reshape(n, 1)).item()
@@ -518,27 +518,42 @@ def test_multi_consumer_gradients_ride_in_gemm_epilogues():
             assert ((p.grad - g2[k].grad).norm() / g2[k].grad.norm().clamp_min(1e-30)).item() < 2e-2, k      # a lost gradient would be O(1)
 
 
-def test_compact_skip_branch_equals_materialised():
+@pytest.mark.parametrize("D", [3, 4, 12])
+def test_compact_skip_branch_equals_materialised(D):
     """Decoder_fuse evaluates the nearest-up-sampled skip channels' share of d*_c2 on a compact depth grid (three depth classes per
     up-sampling block) and broadcasts it; with the switch off it materialises the up-sampled tensor and the concat buffer as the
     reference does (mmvit4.py:271-287).  Same arithmetic up to the order of the channel sum: prediction and every gradient agree to
-    fp32 rounding amplified by the InstanceNorm chain.  4 bands: levels 1-3 (f = 32, 16, 8) take the compact path."""
-    case = dict(B=2, D=4, H=64, W=64, mode="train_nodrop", conv_gain=1.0, wseed=9)
+    fp32 rounding amplified by the InstanceNorm chain.  4 bands: levels 1-3 (f = 32, 16, 8) take the compact path; 3 bands (the
+    reference-native depth, F8_IMAGES4.py:87) and 12 bands (BASELINE configs[4]) do not divide the 16^3..128^3 grids: blocks of
+    floor / ceil(n / D) slices (levels 1-3 at 3 bands: 42.7 / 21.3 / 10.7 slices per block; levels 1 at 12 bands: 10.7)."""
+    case = dict(B=2, D=D, H=64, W=64, mode="train_nodrop", conv_gain=1.0, wseed=9)
     import ops
     res = []
     for compact in (True, False):
-        model, _ = build_hip(case)
+        model, sd = build_hip(case)
         model.decoder_fuse.compact_skips = compact
         x, mask = helpers.make_inputs(case["B"], case["D"], case["H"], case["W"])
         pred = model(x.to(DEV))
         ops.bce_with_logits_mean(pred, mask.to(DEV)).backward()
         torch.cuda.synchronize()
-        res.append((pred.detach(), {k: p.grad for k, p in model.named_parameters() if p.grad is not None}))
+        res.append((pred.detach(), {k: p.grad.double() for k, p in model.named_parameters() if p.grad is not None}))
+        del model, pred
     (p1, g1), (p2, g2) = res
     assert (p1 - p2).abs().max().item() < 2e-5
     assert g1.keys() == g2.keys()
-    worst = max(((g1[k] - g2[k]).norm() / g2[k].norm().clamp_min(1e-30)).item() for k in g1)
-    assert worst < 2e-3, worst
+    # The two paths are two fp32 realisations of the same arithmetic (the channel sum of d*_c2 associated differently), so per tensor
+    # they may differ by about the sum of their own rounding errors - which depends on the tensor's conditioning (1e-6 for the decoder
+    # head, 1e-2 for biases in front of a normalisation).  The bar is therefore tied, tensor by tensor, to the materialised path's OWN
+    # error against the fp64 truth (the oracle's modules on the device in fp64): |compact - materialised| <= 4 x that error + 1e-6.
+    truth = _oracle_on_device(case, torch.float64, sd, all_grads=True)["grads"]
+    bad = []
+    for k in g1:
+        nrm = truth[k].norm().clamp_min(1e-30)
+        diff = ((g1[k] - g2[k]).norm() / nrm).item()
+        own = ((g2[k] - truth[k]).norm() / nrm).item()
+        if diff > 4 * own + 1e-6:
+            bad.append((k, diff, own))
+    assert not bad, bad[:10]
 
 
 def test_determinism():

@@ -81,6 +81,8 @@ def main():
         c = cap.get(name)
         if c is None or "gy" not in c:
             continue
+        if isinstance(mod, nn.Conv3d) and (mod.out_channels & 3):
+            continue                       # final_conv (8 -> 3) runs inside ops.head, not as a convolution launch
         # fp64 local truth of this layer from the captured input / incoming gradient (the captured x-gradient is the TOTAL over all
         # consumers of x, so the local one is recomputed in fp64 too)
         m64 = copy.deepcopy(mod)
@@ -111,8 +113,7 @@ def main():
                 yh = ops.conv3d(xs, w, b, mod.stride, mod.padding, False)
                 xh = xs
             else:
-                yh = ops.conv3d(xh, w, b, mod.stride, mod.padding if mod.padding_mode == "zeros" else (1, 1, 1),
-                                mod.padding_mode == "replicate" and mod.kernel_size != (1, 1, 1))
+                yh = ops.conv3d(xh, w, b, mod.stride, mod.padding, mod.padding_mode == "replicate" and mod.kernel_size != (1, 1, 1))
         elif isinstance(mod, nn.BatchNorm3d):
             rm, rv = torch.zeros_like(w), torch.ones_like(w)
             yh = ops.batch_norm(xh, w, b, rm, rv, None, False, False, True, 0.1, mod.eps)

@@ -1,12 +1,13 @@
 """Two-level stream fork inside a HIP-graph capture, reduced to raw streams / events and trivial kernels (one case per process).
 
-    python -X faulthandler tools/probe/graph_fork2.py raw|alloc|origin|join1|onelane|model
+    python -X faulthandler tools/probe/graph_fork2.py raw|alloc|origin|origin_lane|join1|onelane|model
 
 raw    : capture stream C forks lane streams L0, L1; each lane forks its own side stream S; S joins L through four events (the decoder's
          skip branch pattern), L joins C.  Pre-allocated tensors, torch element-wise kernels only.
          ROCm 7.2 / torch 2.10: SEGFAULT inside hipStreamEndCapture (gpurun_out/r3a_graph_raw.log) - a runtime bug, no product code involved.
 alloc  : the same topology with tensors allocated (and dropped) inside the capture on the forked streams (same segfault).
 origin : S forks from the ORIGIN stream C instead of from its lane (no second fork level); it still joins its lane L.
+origin_lane: S waits for the origin's event FIRST and then for an event of its lane (what Decoder_fuse.forward does).
 join1  : nested fork as in `raw`, but S joins L through ONE event (its last) instead of four.
 onelane: nested fork as in `raw` with a single lane.
 model  : the product's own two-lane forward (MMVit4 with decoder_split = 2, batch 4) captured by train.GraphedForward.
@@ -28,7 +29,7 @@ def say(*a):
     print("[graph_fork2:%s]" % case, *a, flush=True)
 
 
-def topology(alloc, origin_fork=False, one_join=False, lanes=2):
+def topology(alloc, origin_fork=False, one_join=False, lanes=2, then_lane=False):
     C = torch.cuda.Stream()
     L = [torch.cuda.Stream() for _ in range(lanes)]
     S = [torch.cuda.Stream() for _ in range(lanes)]
@@ -43,7 +44,7 @@ def topology(alloc, origin_fork=False, one_join=False, lanes=2):
             if origin_fork:
                 S[k].wait_event(e)
             with torch.cuda.stream(L[k]):
-                if not origin_fork:
+                if not origin_fork or then_lane:
                     e2 = torch.cuda.Event(); keep.append(e2); e2.record(L[k]); S[k].wait_event(e2)
                 evs = []
                 with torch.cuda.stream(S[k]):
@@ -81,8 +82,9 @@ def topology(alloc, origin_fork=False, one_join=False, lanes=2):
         say("eager after capture ok", bool(torch.equal(again, ref)))
 
 
-if case in ("raw", "alloc", "origin", "join1", "onelane"):
-    topology(case == "alloc", origin_fork=case == "origin", one_join=case == "join1", lanes=1 if case == "onelane" else 2)
+if case in ("raw", "alloc", "origin", "origin_lane", "join1", "onelane"):
+    topology(case == "alloc", origin_fork=case.startswith("origin"), one_join=case == "join1", lanes=1 if case == "onelane" else 2,
+             then_lane=case == "origin_lane")
 else:
     import mmvit4
     import train
