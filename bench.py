@@ -133,6 +133,100 @@ class MfmaTimer:
         return fl, ms, len(self.rec)
 
 
+class HbmTimer:
+    """per-launch HIP-event timing of the HBM-bound kernel families (normalisation passes, resampling, pooling, the inter-modal
+    correlation, dropout, ...) in the same single-stream pass MfmaTimer uses: a proxy in front of the ctypes library records (bytes,
+    start, stop) for the entry points below.  `bytes` = ALGORITHMIC bytes of the call (every tensor it has to read or write, once), so
+    GB/s against the 8 TB/s HBM3E peak is the roofline fraction of these kernels (BASELINE north_star: "achieved HBM GB/s")."""
+
+    @staticmethod
+    def _n(v):
+        return 0 if v is None else int(getattr(v, "value", v) or 0)
+
+    def __init__(self, H):
+        n = self._n
+        self.H, self.real, self.rec, self.on = H, H.lib(), [], False
+
+        def norm_apply(a):       # (x, ldx, mean, rstd, gamma, beta, residual, ldr, y, ldy, rpg, G, C, ...)
+            return 4 * n(a[10]) * n(a[11]) * n(a[12]) * (2 + (1 if n(a[6]) else 0))
+
+        def norm_bwd(a, pre):    # (dy, lddy, y, ldy, x, ldx, mean, rstd, gamma, dx, lddx, dres, lddres, dgamma, dbeta, rpg, G, C, ...)
+            if pre and len(a) == 22:                        # corrif_norm_bwd_pre: (..., rows, C, flags, part, chunks, ws, stream)
+                e = n(a[15]) * n(a[16])
+            else:
+                e = n(a[15]) * n(a[16]) * n(a[17])
+            y = 1 if n(a[2]) else 0
+            apply_ = 2 + y + (1 if n(a[9]) else 0) + (1 if n(a[11]) else 0)
+            return 4 * e * (apply_ + (0 if pre else 2 + y))
+
+        def resample(a):         # (x, ldx, y, ldy, B, C, Di, Hi, Wi, Do, Ho, Wo, stream)
+            return 4 * n(a[4]) * n(a[5]) * (n(a[6]) * n(a[7]) * n(a[8]) + n(a[9]) * n(a[10]) * n(a[11]))
+
+        self.models = {
+            "corrif_norm_apply": ("norm_apply", norm_apply), "corrif_norm_apply_g": ("norm_apply", norm_apply),
+            "corrif_norm_bwd": ("norm_bwd", lambda a: norm_bwd(a, False)), "corrif_norm_bwd_g": ("norm_bwd", lambda a: norm_bwd(a, False)),
+            "corrif_norm_bwd_pre": ("norm_bwd", lambda a: norm_bwd(a, True)), "corrif_norm_bwd_pre_g": ("norm_bwd", lambda a: norm_bwd(a, True)),
+            "corrif_norm_stats": ("norm_stats", lambda a: 4 * n(a[2]) * n(a[3]) * n(a[4])),
+            "corrif_norm_stats_g": ("norm_stats", lambda a: 4 * n(a[2]) * n(a[3]) * n(a[4])),
+            "corrif_trilinear_fwd": ("trilinear", resample), "corrif_trilinear_bwd": ("trilinear", resample),
+            "corrif_nearest_fwd": ("nearest", resample), "corrif_nearest_bwd": ("nearest", resample),
+            "corrif_maxpool133_fwd": ("maxpool", lambda a: n(a[3]) * n(a[4]) * n(a[7]) * (4 * n(a[5]) * n(a[6]) + 5 * ((n(a[5]) - 1) // 2 + 1) * ((n(a[6]) - 1) // 2 + 1))),
+            "corrif_maxpool133_bwd": ("maxpool", lambda a: n(a[3]) * n(a[4]) * n(a[7]) * (4 * n(a[5]) * n(a[6]) + 5 * ((n(a[5]) - 1) // 2 + 1) * ((n(a[6]) - 1) // 2 + 1))),
+            "corrif_intercorr_fwd": ("inter_corr", lambda a: 4 * 12 * n(a[8]) * n(a[9]) * n(a[10])),
+            "corrif_intercorr_bwd": ("inter_corr", lambda a: 4 * 21 * n(a[11]) * n(a[12]) * n(a[13])),
+            "corrif_dropout": ("dropout", lambda a: 8 * n(a[2])),
+            "corrif_add": ("add", lambda a: 12 * n(a[3])),
+            "corrif_copy2d": ("copy", lambda a: 8 * n(a[4]) * n(a[5])),
+            "corrif_layernorm_fwd": ("layernorm", lambda a: 4 * n(a[9]) * n(a[10]) * (2 + (1 if n(a[3]) else 0))),
+            "corrif_layernorm_bwd": ("layernorm", lambda a: 12 * n(a[9]) * n(a[10])),
+            "corrif_gelu_fwd": ("gelu", lambda a: 8 * n(a[2])), "corrif_gelu_bwd": ("gelu", lambda a: 12 * n(a[3])),
+            "corrif_depth_bcast_add": ("depth_class", lambda a: 8 * n(a[4]) * n(a[5]) * n(a[6]) * n(a[7])),
+            "corrif_depth_class_reduce": ("depth_class", lambda a: 4 * n(a[4]) * n(a[5]) * n(a[6]) * n(a[7])),
+            "corrif_conv1x1_small_fwd": ("conv1x1_small", lambda a: 4 * n(a[7]) * (n(a[8]) + n(a[9]))),
+            "corrif_head_fwd": ("head", lambda a: 4 * n(a[4]) * n(a[5]) * 11), "corrif_head_bwd": ("head", lambda a: 4 * n(a[8]) * n(a[9]) * 22),
+        }
+        outer = self
+
+        class Proxy:
+            def __getattr__(self, name):
+                fn = getattr(outer.real, name)
+                m = outer.models.get(name)
+                if m is None:
+                    return fn
+
+                def timed(*a):
+                    if not outer.on:
+                        return fn(*a)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    r = fn(*a)
+                    e1.record()
+                    outer.rec.append((m[0], m[1](a), e0, e1))
+                    return r
+                return timed
+        H._lib = Proxy()
+
+    def close(self):
+        self.H._lib = self.real
+
+    def by_family(self, overhead_ms, steps):
+        agg = {}
+        for fam, nbytes, e0, e1 in self.rec:
+            d = agg.setdefault(fam, [0.0, 0.0, 0])
+            d[0] += max(e0.elapsed_time(e1) - overhead_ms, 0.0)
+            d[1] += nbytes
+            d[2] += 1
+        out = {k: {"ms_per_step": round(v[0] / steps, 2), "GB_per_step": round(v[1] / steps / 1e9, 2),
+                   "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 0) if v[0] > 0 else 0.0,
+                   "frac_of_8TBps": round(v[1] / (v[0] * 1e-3) / 8e12, 3) if v[0] > 0 else 0.0, "launches_per_step": v[2] // steps}
+               for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+        t = sum(v[0] for v in agg.values())
+        b = sum(v[1] for v in agg.values())
+        out["_all"] = {"ms_per_step": round(t / steps, 2), "GB_per_step": round(b / steps / 1e9, 1),
+                       "GBps": round(b / (t * 1e-3) / 1e9, 0) if t > 0 else 0.0, "frac_of_8TBps": round(b / (t * 1e-3) / 8e12, 3) if t > 0 else 0.0}
+        return out
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -214,6 +308,7 @@ def main():
     from data_parallel import GradAllReducer, broadcast_module_state
     ops.lib()                                           # fail loudly if the HIP library is missing
     timer = None if args.no_kernel_timing else MfmaTimer(ops)
+    hbm = None if args.no_kernel_timing else HbmTimer(corrif_hip)
 
     torch.manual_seed(0)
     model = mmvit4.MMVit4().to(dev).train()
@@ -284,6 +379,7 @@ def main():
         # per-launch durations of the MFMA kernels: HIP events around every launch, in an extra pass right after the timed
         # region with the three modality branches serialised on one stream (with concurrent streams an event pair also
         # spans the other streams' kernels, so per-kernel durations are only meaningful one stream at a time)
+        grouped_was, model.grouped_encoders = model.grouped_encoders, model.encoders_grouped_for(x)     # the timed region's encoder schedule
         model.concurrent_branches = False
         side_was, ops.SIDE_WGRAD = ops.SIDE_WGRAD, False
         sideg_was, ops.SIDE_WGRAD_GROUPED = ops.SIDE_WGRAD_GROUPED, False
@@ -298,12 +394,13 @@ def main():
         for _ in range(kt_steps):
             for _ in range(80):
                 timer._gemm(ga.data_ptr(), 4096, gb.data_ptr(), 4096, 1, gc.data_ptr(), 4096, 4096, 4096, 4096, 4096, gg)
-            timer.on = True
+            timer.on = hbm.on = True
             step()
-            timer.on = False
+            timer.on = hbm.on = False
         torch.cuda.synchronize()
         del ga, gb, gc
         model.concurrent_branches = True
+        model.grouped_encoders = grouped_was
         ops.SIDE_WGRAD = side_was
         ops.SIDE_WGRAD_GROUPED = sideg_was
         model.decoder_split = split_was
@@ -325,7 +422,9 @@ def main():
                "config": {"workload": "mmvit4 CorrIFNet fwd+loss+bwd, %d bands/modality, %dx%d, batch %d per GPU, train mode %s"
                                       % (args.bands, args.size, args.size, B, label),
                           "global_batch": world * B, "parallelism": "dp%d" % world, "loss": float(loss.item()),
-                          "peak_mem_GB": round(peak_mem / 1e9, 2)}}
+                          "peak_mem_GB": round(peak_mem / 1e9, 2),
+                          "encoder_schedule": "grouped (one launch per twin layer of the three modality encoders)"
+                                              if model.encoders_grouped_for(x) else "per modality on three streams"}}
         # HBM bytes of the MFMA kernel family for ONE step of this workload, from the newest committed rocprofv3 PMC passes
         # (profiles/r??_mfma_traffic.json).  Quoted only while the kernel sources still are the ones the counters were taken with
         # (sha1 of csrc/ stored by tools/reduce_traffic.py); otherwise null - a stale number is worse than none.
@@ -376,6 +475,8 @@ def main():
                                          "achieved = launched flops of a step / that kernel time" % kt_steps,
                                "event_pair_overhead_us": round(ovh * 1e3, 2),
                                "families": timer.by_kind(ovh, max(kt_steps, 1)),
+                               # the HBM-bound kernel families: algorithmic bytes of every launch / its HIP-event duration, against 8 TB/s
+                               "hbm_families": hbm.by_family(ovh, max(kt_steps, 1)),
                                "whole_step_frac": round(algo / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if algo else None}
         if timer and args.dump_shapes:
             with open(args.dump_shapes, "w") as f:

@@ -36,7 +36,8 @@ class Gemm(C.Structure):
                 ("stats_part", ptr), ("stats_rows_per_group", i64), ("stats_relu", i32), ("ws", ptr), ("no_split", i32),
                 ("addend2", ptr), ("ld_add2", i64),
                 ("bstats_x", ptr), ("bstats_ldx", i64), ("bstats_y", ptr), ("bstats_ldy", i64), ("bstats_mean", ptr), ("bstats_rstd", ptr),
-                ("zs_bias", i64), ("zs_add", i64), ("zs_add2", i64), ("zs_stats", i64), ("zs_bsx", i64), ("zs_bsy", i64), ("zs_bsstat", i64)]
+                ("zs_bias", i64), ("zs_add", i64), ("zs_add2", i64), ("zs_stats", i64), ("zs_bsx", i64), ("zs_bsy", i64), ("zs_bsstat", i64),
+                ("no_ksplit", i32)]
 
 
 class Wgrad(C.Structure):
@@ -48,7 +49,8 @@ class Wgrad(C.Structure):
 class Conv3Patch(C.Structure):
     _fields_ = [("X", ptr), ("ldx", i64), ("Wp", ptr), ("Y", ptr), ("ldy", i64), ("bias", ptr),
                 ("B", i32), ("Sd", i32), ("Sh", i32), ("Sw", i32), ("Od", i32), ("Oh", i32), ("Ow", i32),
-                ("Ci", i32), ("Co", i32), ("pad", i32), ("clamp", i32), ("cc", i32), ("fold", i32)]
+                ("Ci", i32), ("Co", i32), ("pad", i32), ("clamp", i32), ("cc", i32), ("fold", i32),
+                ("stats_part", ptr), ("stats_chunks", i32), ("stats_relu", i32), ("add_src", ptr), ("ld_add", i64), ("add_Ds", i32)]
 
 
 class Conv3PatchWgrad(C.Structure):
@@ -67,6 +69,7 @@ _SIGS = {
     "corrif_wgrad_plan": (i32, [i32, i32, i32, i32]),
     "corrif_conv3_patch": (i32, [C.POINTER(Conv3Patch), ptr]),
     "corrif_conv3_patch_cc": (i32, [i32, i32]),
+    "corrif_conv3_patch_stats_chunks": (i32, [i32, i32, i32, i32]),
     "corrif_conv3_patch_wgrad": (i32, [C.POINTER(Conv3PatchWgrad), ptr]),
     "corrif_conv3_patch_wgrad_workspace": (C.c_size_t, [i32, i32]),
     "corrif_conv3_patch_wgrad_slots": (i32, [i32, i32]),
@@ -89,6 +92,8 @@ _SIGS = {
     "corrif_norm_bwd": (i32, [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, ptr, i64, i32, i32, i32, i32, ptr, ptr]),
     "corrif_norm_bwd_pre": (i32, [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, ptr, i64, i32, i32, ptr, i32, ptr, ptr]),
     "corrif_norm_workspace": (C.c_size_t, [i64, i32, i32]),
+    "corrif_norm_workspace_g": (C.c_size_t, [i64, i32, i32]),
+    "corrif_conv3_patch_stats_supported": (i32, [i32, i32]),
     "corrif_norm_stats_g": (i32, [ptr, i64, i64, i32, i32, i32, f32, ptr, ptr, ptr, ptr, f32, ptr, ptr]),
     "corrif_norm_stats_finalize_g": (i32, [ptr, i32, i32, i32, i64, f32, ptr, ptr, ptr, ptr, f32, ptr]),
     "corrif_norm_apply_g": (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, i64, i64, i32, i32, i32, i64, ptr]),
@@ -96,6 +101,7 @@ _SIGS = {
     "corrif_norm_bwd_pre_g": (i32, [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, ptr, i64, i32, i32, i32, i64, ptr, i32, ptr, ptr]),
     "corrif_col_sum_g": (i32, [ptr, i64, i64, i32, i32, ptr, ptr, ptr]),
     "corrif_stack_groups": (i32, [ptr, i32, ptr, i64, ptr]),
+    "corrif_gather_multi": (i32, [ptr, ptr, ptr, i32, ptr, ptr]),
     "corrif_layernorm_fwd": (i32, [ptr, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, f32, ptr]),
     "corrif_layernorm_bwd": (i32, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr]),
     "corrif_layernorm_workspace": (C.c_size_t, [i64, i32]),

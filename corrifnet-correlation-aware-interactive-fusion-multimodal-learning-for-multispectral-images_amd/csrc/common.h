@@ -120,3 +120,27 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
     return cdf + x * kInvSqrt2Pi * expf(-0.5f * x * x);
 }
+
+// ---- depth axis of a nearest-neighbour up-sampling Ds -> D slices (F.interpolate(nearest), same float arithmetic as nearest_fwd_kernel)
+// and the depth classes of the decoder's compact skip branch (misc.hip: depth_bcast_add / depth_class_reduce; conv3_patch.hip: fused add)
+struct DAxis { int in, out; float scale; };      // the depth axis of nearest_fwd_kernel (same float arithmetic)
+static DAxis make_daxis(int in, int out) { DAxis a; a.in = in; a.out = out; a.scale = (float)in / (float)out; return a; }
+__device__ __forceinline__ int depth_src(const DAxis& a, int o) {
+    int s = (int)floorf((float)o * a.scale);
+    return s < a.in - 1 ? s : a.in - 1;
+}
+__device__ __forceinline__ int depth_class(int d, const DAxis& a) {
+    const int k = depth_src(a, d);
+    const bool first = d == 0 || depth_src(a, d - 1) != k, last = d == a.out - 1 || depth_src(a, d + 1) != k;
+    return 3 * k + (first ? 0 : (last ? 2 : 1));
+}
+// first / last slice of block k (the slices whose source is k)
+__device__ __forceinline__ void depth_block(const DAxis& a, int k, int& lo, int& hi) {
+    const float inv = 1.0f / a.scale;
+    lo = (int)floorf((float)k * inv) - 1;
+    hi = (int)ceilf((float)(k + 1) * inv) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > a.out - 1) hi = a.out - 1;
+    while (lo <= hi && depth_src(a, lo) != k) ++lo;
+    while (hi >= lo && depth_src(a, hi) != k) --hi;
+}

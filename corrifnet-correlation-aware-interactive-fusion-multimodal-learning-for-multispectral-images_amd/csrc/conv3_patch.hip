@@ -25,6 +25,14 @@ struct PatchArgs {
     int ltd, lth, ltw, ntd, nth, ntw;
     FastDiv dHW, dW;                 // patch voxel index -> (pd, ph, pw)
     FastDiv dT0, dT1, dT2;           // tile index -> (b, td, th, tw)
+    // fused epilogue extras (forward of a general_conv3d_prenorm layer, mmvit4.py:41-45):
+    //   add_src: y += add_src[b, cls(d), h, w, :]  - the compact skip branch's share of d*_c2 (depth classes, see common.h) - the separate
+    //            depth_bcast_add pass over the full-depth tensor disappears;
+    //   stats:   per (sample, channel) sum / sum of squares of max(y, 0) for the InstanceNorm that follows, partial per (workgroup, wave)
+    //            slot: stats[((b*Co + c)*stats_chunks + slot*4 + wave)*2 + {0,1}] (pre-zeroed; corrif_norm_stats_finalize reads it) -
+    //            the separate statistics pass over the conv output disappears.
+    const float* add_src; int64_t ld_add; DAxis add_ax;
+    double* stats; int stats_chunks, stats_relu, tiles_per_sample;
 };
 
 template <int NG, int CC>
@@ -87,8 +95,10 @@ __device__ __forceinline__ void patch_chunk(f32x4 (&acc)[NG], const float* __res
 // stores and two barriers instead of exposed HBM/L2 round trips.  Loads are unconditional from the clamped voxel (always
 // mapped) and zero padding is applied at the LDS store: a load under a branch makes the compiler drain vmcnt at the join.
 // NPF = halo float4 per thread: ceil(648 * CC/4 / 256) for the usual 4 x 4 x 16 tile, ceil(972 * ...) for the shallow-grid tiles.
-template <int NG, int CC, int NPF>
-__global__ __launch_bounds__(256) void conv3_patch_kernel(PatchArgs p) {
+// ST: the variant with the fused InstanceNorm statistics (forward of the 8- / 16-channel layers at 128^3 / 64^3, where the separate
+// statistics pass costs most); its accumulators must not cost the data-gradient launches of the same kernel their registers.
+template <int NG, int CC, int NPF, bool ST = false>
+__global__ __launch_bounds__(256, ST ? 2 : 1) void conv3_patch_kernel(PatchArgs p) {
     using Cfg = PatchCfg<NG, CC>;
     constexpr int C4 = CC / 4;
     constexpr int K4 = Cfg::KC / 4;
@@ -175,6 +185,34 @@ __global__ __launch_bounds__(256) void conv3_patch_kernel(PatchArgs p) {
     f32x4 acc[NA];
 #pragma unroll
     for (int g = 0; g < NA; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // fused InstanceNorm statistics: fp32 per-lane running sums over this workgroup's tiles of ONE sample (<= a few hundred values per
+    // lane; the lane sums' rounding errors are independent and average out over the 256 lanes x workgroups that are then combined in
+    // double), flushed whenever the sample changes and at the end
+    constexpr int NS = ST ? NG : 1;
+    f32x4 s1[NS], s2[NS];
+#pragma unroll
+    for (int g = 0; g < NS; ++g) { s1[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; s2[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    int stat_b = -1;
+    auto flush_stats = [&]() {
+        if (!ST || stat_b < 0) return;
+        const int slot = (int)blockIdx.x - (int)(((int64_t)stat_b * p.tiles_per_sample) / per);
+#pragma unroll
+        for (int g = 0; g < NS; ++g) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double a = (double)s1[g][e], q = (double)s2[g][e];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+                if (lane == 0 && g * 4 + e < p.Co) {
+                    double* o2 = p.stats + ((((int64_t)stat_b * p.Co + g * 4 + e) * p.stats_chunks) + slot * 4 + wave) * 2;
+                    o2[0] = a;
+                    o2[1] = q;
+                }
+            }
+            s1[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            s2[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
 
     if (nitems > 0) issue(t_begin, 0, !p.wres);
     int tile = t_begin, ch = 0;
@@ -208,14 +246,32 @@ __global__ __launch_bounds__(256) void conv3_patch_kernel(PatchArgs p) {
             const uint32_t itw = t - ith * p.dT2.d;
             const int od = (int)(itd << p.ltd) + vd, oh = (int)(ith << p.lth) + vh, ow = (int)(itw << p.ltw) + vw;
             if (!p.fold) {
+                if constexpr (ST) {
+                    if ((int)b != stat_b) {                   // uniform per workgroup: the tile's sample index
+                        flush_stats();
+                        stat_b = (int)b;
+                    }
+                }
                 if (od < p.Od && oh < p.Oh && ow < p.Ow) {
                     const int64_t row = (((int64_t)b * p.Od + od) * p.Oh + oh) * p.Ow + ow;
+                    const float* __restrict__ addrow = nullptr;
+                    if (p.add_src)
+                        addrow = p.add_src + ((((int64_t)b * 3 * p.add_ax.in + depth_class(od, p.add_ax)) * p.Oh + oh) * p.Ow + ow) * p.ld_add;
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
                         if (g * 4 >= p.Co) continue;
                         f32x4 v = acc[g];
                         v += *reinterpret_cast<const f32x4*>(biasl + g * 4);       // LDS copy: a global load here would wait for the prefetch in flight
+                        if (addrow) v += *reinterpret_cast<const f32x4*>(addrow + g * 4);
                         *reinterpret_cast<f32x4*>(p.Y + row * p.ldy + g * 4) = v;
+                        if constexpr (ST) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float t = p.stats_relu ? fmaxf(v[e], 0.f) : v[e];
+                                s1[g][e] += t;
+                                s2[g][e] = fmaf(t, t, s2[g][e]);
+                            }
+                        }
                     }
                 }
             } else {
@@ -253,13 +309,22 @@ __global__ __launch_bounds__(256) void conv3_patch_kernel(PatchArgs p) {
         tile = ntile;
         ch = nch;
     }
+    if constexpr (ST) flush_stats();
 }
 
-template <int NG, int CC, int NPF>
+extern "C" int corrif_conv3_patch_cc(int32_t Ci, int32_t Co);
+template <int NG, int CC>
+static constexpr bool patch_stats_variant() { return (NG == 2 && (CC == 16 || CC == 8)) || (NG == 4 && CC == 8); }
+extern "C" int corrif_conv3_patch_stats_supported(int32_t Ci, int32_t Co) {
+    const int cc = corrif_conv3_patch_cc(Ci, Co);
+    return cc != 0 && (Co == 8 || (Co == 16 && cc == 8));
+}
+
+template <int NG, int CC, int NPF, bool ST>
 static int launch_patch_npf(const PatchArgs& a, unsigned tiles, size_t lds, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_patch_kernel<NG, CC, NPF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_patch_kernel<NG, CC, NPF, ST>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess) {
             (void)hipGetLastError();
             return CORRIF_ELAUNCH;
@@ -268,7 +333,12 @@ static int launch_patch_npf(const PatchArgs& a, unsigned tiles, size_t lds, hipS
     }
     const unsigned per_cu = lds > 80 * 1024 ? 1 : 2;                     // co-resident workgroups per CU (LDS bound)
     const unsigned grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
-    hipLaunchKernelGGL((conv3_patch_kernel<NG, CC, NPF>), dim3(grid), dim3(256), lds, s, a);
+    if (a.stats) {      // the partial-slot layout the caller sized with corrif_conv3_patch_stats_chunks assumes at most 512 workgroups
+        const int64_t per = ((int64_t)tiles + grid - 1) / grid;
+        const int64_t nslots = (a.tiles_per_sample + per - 1) / per + 1;
+        if (4 * nslots > a.stats_chunks) return CORRIF_EINVAL;
+    }
+    hipLaunchKernelGGL((conv3_patch_kernel<NG, CC, NPF, ST>), dim3(grid), dim3(256), lds, s, a);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
@@ -284,8 +354,15 @@ static int launch_patch(const PatchArgs& a, unsigned tiles, int npv, hipStream_t
     const size_t lds = fixed + (b.wres ? nchunk : 1) * wchunk;
     if (lds > 160 * 1024) return CORRIF_EUNSUPPORTED;
     constexpr int C4 = CC / 4, NPF_STD = (648 * C4 + 255) / 256, NPF_MAX = (972 * C4 + 255) / 256;
-    if (npv * C4 <= NPF_STD * 256) return launch_patch_npf<NG, CC, NPF_STD>(b, tiles, lds, s);
-    if (npv * C4 <= NPF_MAX * 256) return launch_patch_npf<NG, CC, NPF_MAX>(b, tiles, lds, s);
+    if (a.stats) {
+        if constexpr (patch_stats_variant<NG, CC>()) {
+            if (npv * C4 <= NPF_STD * 256) return launch_patch_npf<NG, CC, NPF_STD, true>(b, tiles, lds, s);
+            if (npv * C4 <= NPF_MAX * 256) return launch_patch_npf<NG, CC, NPF_MAX, true>(b, tiles, lds, s);
+        }
+        return CORRIF_EUNSUPPORTED;
+    }
+    if (npv * C4 <= NPF_STD * 256) return launch_patch_npf<NG, CC, NPF_STD, false>(b, tiles, lds, s);
+    if (npv * C4 <= NPF_MAX * 256) return launch_patch_npf<NG, CC, NPF_MAX, false>(b, tiles, lds, s);
     return CORRIF_EUNSUPPORTED;
 }
 
@@ -295,6 +372,24 @@ extern "C" int corrif_conv3_patch_cc(int32_t Ci, int32_t Co) {
     if (Co <= 0 || Co > 32 || (Co & 3) || Ci <= 0 || (Ci & 7)) return 0;
     if (Ci > 64) return 0;      // many channel chunks re-stage the halo too often: the implicit GEMM is faster there (d3_c2: 50 vs 38 TF/s)
     return (Co <= 8 && !(Ci & 15)) ? 16 : 8;     // measured: 8-channel chunks (more co-resident workgroups) are not faster for Cout <= 8
+}
+
+// number of statistics partial slots per (sample, channel) a forward launch on this output grid may use (CorrifConv3Patch.stats_chunks):
+// 4 waves x (workgroups that can touch one sample); the launch never uses more than 512 workgroups
+extern "C" int corrif_conv3_patch_stats_chunks(int32_t B, int32_t Od, int32_t Oh, int32_t Ow) {
+    if (B <= 0 || Od <= 0 || Oh <= 0 || Ow <= 0) return 0;
+    int TD = 4, TH = 4, TW = 16;
+    if (Od < 4) { TD = Od >= 2 ? 2 : 1; TH = 256 / (TD * TW); }
+    const int64_t tps = (int64_t)((Od + TD - 1) / TD) * ((Oh + TH - 1) / TH) * ((Ow + TW - 1) / TW);
+    const int64_t tiles = tps * B;
+    int64_t worst = 0;
+    for (int64_t grid = 256; grid <= 512; grid += 256) {       // 1 or 2 workgroups per CU, or one per tile when there are fewer tiles
+        const int64_t g = tiles < grid ? tiles : grid;
+        const int64_t per = (tiles + g - 1) / g;
+        const int64_t n = (tps + per - 1) / per + 1;
+        if (n > worst) worst = n;
+    }
+    return (int)(4 * worst);
 }
 
 extern "C" int corrif_conv3_patch(const CorrifConv3Patch* q, void* stream) {
@@ -310,6 +405,11 @@ extern "C" int corrif_conv3_patch(const CorrifConv3Patch* q, void* stream) {
     a.X = q->X; a.ldx = q->ldx; a.Wp = q->Wp; a.Y = q->Y; a.ldy = q->ldy; a.bias = q->bias;
     a.B = q->B; a.Sd = q->Sd; a.Sh = q->Sh; a.Sw = q->Sw; a.Od = q->Od; a.Oh = q->Oh; a.Ow = q->Ow;
     a.Ci = q->Ci; a.Co = q->Co; a.pad = q->pad; a.clamp = q->clamp; a.fold = q->fold;
+    a.add_src = q->add_src; a.ld_add = q->ld_add; a.add_ax = make_daxis(q->add_Ds > 0 ? q->add_Ds : 1, q->Od);
+    a.stats = q->stats_part; a.stats_chunks = q->stats_chunks; a.stats_relu = q->stats_relu; a.tiles_per_sample = 0;
+    if (q->add_src && (q->fold || q->add_Ds < 1 || q->Od < 2 * q->add_Ds || (q->ld_add & 3) || q->ld_add < q->Co || ((uintptr_t)q->add_src & 15)))
+        return CORRIF_EINVAL;
+    if (q->stats_part && (q->fold || q->stats_chunks < 4)) return CORRIF_EINVAL;
     if (q->fold) {      // O = (n+2)^3 padded grid, Y = the n^3 gradient; pairs (0,1) / (n,n+1) must share a 4 x 4 x 16 tile
         if (q->pad != 2 || q->clamp || q->bias || q->Od < 6 || ((q->Od - 2) & 3) || ((q->Oh - 2) & 3) || ((q->Ow - 2) & 15)) return CORRIF_EUNSUPPORTED;
     }
@@ -327,6 +427,7 @@ extern "C" int corrif_conv3_patch(const CorrifConv3Patch* q, void* stream) {
     const int64_t tiles = (int64_t)q->B * a.ntd * a.nth * a.ntw;
     if (tiles <= 0 || tiles >= ((int64_t)1 << 31)) return CORRIF_EUNSUPPORTED;
     a.ntiles = (int)tiles;
+    a.tiles_per_sample = a.ntd * a.nth * a.ntw;
     const int NG = (q->Co + 3) / 4;
     const int NPV = PD * PH * PW;
     hipStream_t s = (hipStream_t)stream;

@@ -33,11 +33,26 @@ struct GemmCfg {
     static constexpr int SP = TN * 32 + 4;                       // epilogue staging row pitch (floats)
 };
 
-template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL>
+// KS ("K-split accumulation"): a long K loop accumulates in two levels - every KS_TILES K tiles (512 products) the running MFMA chain is
+// folded into a second accumulator set and restarted.  One fp32 fma chain over all of K loses accuracy like sqrt(K): measured per layer
+// against fp64 (tools/local_error.py, round 3) the forward / data-gradient error of this kernel was 1.0x ATen's at K <= 512, 1.9x at
+// 1024, 2.6x at 2048, 3.4x at 4096 and 4.5x at 4608-8640 (oneDNN's blocked accumulation stays flat) - the source of the HIP path's
+// systematically ~1.5x larger end-to-end gradient error.  Costs 16*TM*TN registers and ~1 % of the loop.
+#define KS_TILES 16
+template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL, bool KS = false>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, const float* __restrict__ A, const float* __restrict__ B, float* lds,
                                               const int m0, const int n0, const int kt0, const int kt1,
                                               f32x16 (&acc)[BM / WM / 32][BN / WN / 32]) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    f32x16 tot[KS ? TM : 1][KS ? TN : 1];
+    if constexpr (KS) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+    }
     constexpr int AI = BM / 32, BI = BN / 32;      // float4 chunks per thread per K tile
     constexpr int PBT = BN + 4;                           // row pitch of the K-major B tile (BL == 1)
     float* const As = lds;
@@ -217,7 +232,25 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, const float* __
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
+        if constexpr (KS) {
+            if (((kt - kt0) & (KS_TILES - 1)) == KS_TILES - 1 && kt + 1 < kt1) {      // fold the chain into the second level, restart it
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        tot[i][j] += acc[i][j];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                    }
+            }
+        }
         __syncthreads();
+    }
+    if constexpr (KS) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] += tot[i][j];
     }
 }
 
@@ -363,8 +396,8 @@ struct GemmLds {
     static constexpr int FLOATS = BM * LDS_PITCH + B_FLOATS > 4 * 32 * SP ? BM * LDS_PITCH + B_FLOATS : 4 * 32 * SP;
 };
 
-template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL>
-__global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
+template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL, bool KS = false>
+__global__ __launch_bounds__(256, KS ? 2 : 1) void gemm_fwd_kernel(GemmArgs p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     __shared__ __attribute__((aligned(16))) float lds[GemmLds<BM, BN, WM, WN, BL>::FLOATS];
     const uint32_t tiles_n = (p.N + BN - 1) / BN;
@@ -381,14 +414,14 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(GemmArgs p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    gemm_mainloop<BM, BN, WM, WN, VEC, GEMM, BL>(p, A, B, lds, m0, n0, 0, (p.K + BK - 1) / BK, acc);
+    gemm_mainloop<BM, BN, WM, WN, VEC, GEMM, BL, KS>(p, A, B, lds, m0, n0, 0, (p.K + BK - 1) / BK, acc);
     gemm_epilogue<BM, BN, WM, WN>(p, C, lds, m0, n0, acc, zo);
 }
 
 // unit boundary of stream-K workgroup g: floor(g * U / G)
 __device__ __forceinline__ int64_t sk_bound(int64_t g, int64_t U, int G) { return g * U / G; }
 
-template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL>
+template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL, bool KS = false>
 __global__ __launch_bounds__(256) void gemm_sk_kernel(GemmArgs p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     __shared__ __attribute__((aligned(16))) float lds[GemmLds<BM, BN, WM, WN, BL>::FLOATS];
@@ -415,7 +448,7 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(GemmArgs p) {
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        gemm_mainloop<BM, BN, WM, WN, VEC, GEMM, BL>(p, A, B, lds, m0, n0, k0, k1, acc);
+        gemm_mainloop<BM, BN, WM, WN, VEC, GEMM, BL, KS>(p, A, B, lds, m0, n0, k0, k1, acc);
         if (k0 == 0 && k1 == nk) {
             gemm_epilogue<BM, BN, WM, WN>(p, p.C + zo * p.sC_o + zi * p.sC_i, lds, m0, n0, acc, zo);
             __syncthreads();                                  // the staging area is the next piece's A/B tile
@@ -479,6 +512,7 @@ __global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(GemmArgs p) {
     gemm_epilogue<BM, BN, WM, WN>(p, p.C + zo * p.sC_o + zi * p.sC_i, lds, m0, n0, acc, zo);
 }
 
+#ifndef IGEMM_PROBE_ONLY      // tools/probe/ks_probe.hip compiles single kernel instantiations of this file (register reports in seconds)
 // ---- host side ---------------------------------------------------------------------------------------------------
 // Stream-K plan of one launch: G persistent workgroups (0 = classic one-tile-per-workgroup launch).
 // Classic when the grid already fills the chip many times (ceil() loss < ~6 %) or when there is too little K to split.
@@ -514,25 +548,41 @@ static int sk_plan(int64_t tiles_total, int nk, int slots) {
 
 template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL>
 static int launch_variant(GemmArgs& a, int Z, hipStream_t s, bool plan_only, size_t* ws_bytes) {
-    static int per_cu = 0;
-    if (!per_cu) per_cu = resident_per_cu(gemm_sk_kernel<BM, BN, WM, WN, VEC, GEMM, BL>);
+    // stream-K exists for the two tiles that carry the long-K shapes (128x128, 128x64, float4 loader); the two-level K accumulation for
+    // every float4 tile (the small ones run the small-batch parity cases)
+    constexpr bool BIG = VEC == 4 && BM == 128 && (BN == 128 || BN == 64);
+    constexpr bool KSV = VEC == 4;
     const int64_t tiles_mn = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int nk = (a.K + BK - 1) / BK;
-    const int G = a.sk_allowed ? sk_plan(tiles_mn * Z, nk, num_cus() * per_cu) : 0;
+    int G = 0;
+    if constexpr (BIG) {
+        static int per_cu = 0;
+        if (!per_cu) per_cu = resident_per_cu(gemm_sk_kernel<BM, BN, WM, WN, VEC, GEMM, BL, false>);
+        G = a.sk_allowed ? sk_plan(tiles_mn * Z, nk, num_cus() * per_cu) : 0;
+    }
     if (ws_bytes) *ws_bytes = G ? (size_t)2 * G * BM * BN * sizeof(float) : 0;
     if (plan_only) return CORRIF_OK;
     if (G && !a.sk_ws) return CORRIF_EINVAL;                  // the caller did not provide the workspace corrif_gemm_fwd_workspace asked for
     if (!G) {
         dim3 grid((uint32_t)tiles_mn, 1, Z);
-        hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC, GEMM, BL>), grid, dim3(256), 0, s, a);
+        if constexpr (KSV) {
+            if (nk >= 2 * KS_TILES && !a.ks_off) {            // K >= 1024: two-level accumulation
+                hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC, GEMM, BL, true>), grid, dim3(256), 0, s, a);
+                CORRIF_CHECK_LAUNCH();
+                return CORRIF_OK;
+            }
+        }
+        hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC, GEMM, BL, false>), grid, dim3(256), 0, s, a);
         CORRIF_CHECK_LAUNCH();
         return CORRIF_OK;
     }
-    a.sk_G = G; a.sk_nk = nk; a.sk_tiles_mn = (int)tiles_mn; a.sk_tiles = (int)(tiles_mn * Z);
-    hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, WM, WN, VEC, GEMM, BL>), dim3(G), dim3(256), 0, s, a);
-    CORRIF_CHECK_LAUNCH();
-    hipLaunchKernelGGL((gemm_sk_fixup_kernel<BM, BN, WM, WN>), dim3(G - 1), dim3(256), 0, s, a);
-    CORRIF_CHECK_LAUNCH();
+    if constexpr (BIG) {
+        a.sk_G = G; a.sk_nk = nk; a.sk_tiles_mn = (int)tiles_mn; a.sk_tiles = (int)(tiles_mn * Z);
+        hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, WM, WN, VEC, GEMM, BL, false>), dim3(G), dim3(256), 0, s, a);
+        CORRIF_CHECK_LAUNCH();
+        hipLaunchKernelGGL((gemm_sk_fixup_kernel<BM, BN, WM, WN>), dim3(G - 1), dim3(256), 0, s, a);
+        CORRIF_CHECK_LAUNCH();
+    }
     return CORRIF_OK;
 }
 
@@ -601,6 +651,7 @@ static int gemm_fwd_impl(const CorrifGemm* p, void* stream, bool plan_only, size
     a.om_d = p->om_d; a.om_h = p->om_h; a.om_w = p->om_w; a.oo_d = p->oo_d; a.oo_h = p->oo_h; a.oo_w = p->oo_w;
     a.sk_ws = p->ws; a.sk_G = 0; a.sk_nk = 0; a.sk_tiles = 0; a.sk_tiles_mn = 0;
     a.sk_allowed = p->no_split ? 0 : 1;
+    a.ks_off = p->no_ksplit ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const int Z = p->Z;
     if (scalar) return launch_fwd<128, 64, 2, 2, 1>(a, Z, s, plan_only, ws_bytes);
@@ -638,6 +689,8 @@ extern "C" size_t corrif_gemm_fwd_workspace(const CorrifGemm* p) {
     if (gemm_fwd_impl(p, nullptr, true, &n) != CORRIF_OK) return 0;
     return n;
 }
+
+#endif  // IGEMM_PROBE_ONLY
 
 // ------------------------------------------------------------------------------------------------
 // W-type: contraction over rows.  LDS tiles are [32 rows][BM] and [32 rows][BN]; MFMA lane (i, h)
@@ -819,6 +872,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
 }
 
+#ifndef IGEMM_PROBE_ONLY
 // Row splits of a weight gradient: tiles * splits workgroups should fill the resident workgroup slots of the chip evenly (the kernels
 // run 5 workgroups per CU: 96-102 VGPRs, 26 KB of LDS), but every split also costs a slab of M x N floats written and read back by the
 // reduction.  Cost model: time ~ flops / (fill x 85 TFLOP/s) + 2 x splits x M x N x 4 B / 3 TB/s; the split count with the smallest
@@ -922,3 +976,4 @@ extern "C" int corrif_wgrad(const CorrifWgrad* p, void* stream) {
     }
     return CORRIF_OK;
 }
+#endif  // IGEMM_PROBE_ONLY

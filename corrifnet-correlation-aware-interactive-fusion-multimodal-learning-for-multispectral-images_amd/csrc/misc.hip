@@ -75,27 +75,6 @@ extern "C" int corrif_add_bcast_rows(const float* a, const float* b, int64_t b_n
 // of d*_c2 on a grid of 3 * Ds slices (class c = 3 k + {0 first, 1 interior, 2 last} of block k) and these two kernels broadcast it
 // into / reduce it out of the full-depth tensor:
 //     y[b, d, s, :] += ys[b, cls(d), s, :]        g_ys[b, c, s, :] = sum over d with cls(d) = c of g[b, d, s, :]
-struct DAxis { int in, out; float scale; };      // the depth axis of nearest_fwd_kernel (same float arithmetic)
-static DAxis make_daxis(int in, int out) { DAxis a; a.in = in; a.out = out; a.scale = (float)in / (float)out; return a; }
-__device__ __forceinline__ int depth_src(const DAxis& a, int o) {
-    int s = (int)floorf((float)o * a.scale);
-    return s < a.in - 1 ? s : a.in - 1;
-}
-__device__ __forceinline__ int depth_class(int d, const DAxis& a) {
-    const int k = depth_src(a, d);
-    const bool first = d == 0 || depth_src(a, d - 1) != k, last = d == a.out - 1 || depth_src(a, d + 1) != k;
-    return 3 * k + (first ? 0 : (last ? 2 : 1));
-}
-// first / last slice of block k (the slices whose source is k)
-__device__ __forceinline__ void depth_block(const DAxis& a, int k, int& lo, int& hi) {
-    const float inv = 1.0f / a.scale;
-    lo = (int)floorf((float)k * inv) - 1;
-    hi = (int)ceilf((float)(k + 1) * inv) + 1;
-    if (lo < 0) lo = 0;
-    if (hi > a.out - 1) hi = a.out - 1;
-    while (lo <= hi && depth_src(a, lo) != k) ++lo;
-    while (hi >= lo && depth_src(a, hi) != k) --hi;
-}
 __global__ void depth_bcast_add_kernel(float* __restrict__ y, int64_t ldy, const float* __restrict__ ys, int64_t lds, int64_t total, DAxis ad,
                                        int C4, FastDiv dC, FastDiv dS, FastDiv dD, int S) {
     GRID_STRIDE(i, total) {        // i = ((b * D + d) * S + s) * C4 + c
@@ -1343,6 +1322,30 @@ extern "C" int corrif_adam_multi(const void* table, const int32_t* blk_tensor, c
     double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_multi_kernel, dim3(nblocks_), dim3(256), 0, (hipStream_t)stream, (const AdamEntry*)table, (const int*)blk_tensor,
                        blk_off, (float)((double)lr / bc1), beta1, beta2, eps, weight_decay, (float)sqrt(bc2));
+    CORRIF_CHECK_LAUNCH();
+    return CORRIF_OK;
+}
+
+// ------------------------------------------------------------------ multi-tensor gather: the gradients of one all-reduce bucket in ONE launch
+// table entry per tensor: {src (NULL: the segment is zero-filled), dst offset in the flat bucket, n}; block b copies chunk blk_off[b] (1024
+// elements) of tensor blk_tensor[b].  Replaces autograd's per-parameter in-place accumulation into bucket views (one stock ATen add per
+// parameter and step) and the zero fill of the buckets: the producers write ordinary gradient tensors, the bucket is assembled once.
+struct GatherEntry { const float* src; int64_t dst_off; int64_t n; };
+__global__ __launch_bounds__(256) void gather_multi_kernel(const GatherEntry* __restrict__ tab, const int* __restrict__ blk_tensor,
+                                                           const int64_t* __restrict__ blk_off, float* __restrict__ dst) {
+    const GatherEntry e = tab[blk_tensor[blockIdx.x]];
+    const int64_t base = blk_off[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        if (i >= e.n) break;
+        dst[e.dst_off + i] = e.src ? e.src[i] : 0.f;
+    }
+}
+extern "C" int corrif_gather_multi(const void* table, const int32_t* blk_tensor, const int64_t* blk_off, int32_t nblocks_, float* dst, void* stream) {
+    if (!table || !blk_tensor || !blk_off || !dst || nblocks_ <= 0) return CORRIF_EINVAL;
+    hipLaunchKernelGGL(gather_multi_kernel, dim3(nblocks_), dim3(256), 0, (hipStream_t)stream, (const GatherEntry*)table, (const int*)blk_tensor,
+                       blk_off, dst);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }

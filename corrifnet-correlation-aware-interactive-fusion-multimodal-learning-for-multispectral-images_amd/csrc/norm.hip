@@ -30,6 +30,12 @@ extern "C" size_t corrif_norm_workspace(int64_t rows_per_group, int32_t G, int32
     NormGeo n = norm_geo(rows_per_group, G, C);
     return (size_t)G * n.chunks * C * 2 * sizeof(double) + (size_t)G * C * 2 * sizeof(float) + 64;
 }
+// The grouped (`_g`) entries chunk EVERY group exactly like a standalone launch with G = 1 would (norm_geo(rows, 1, C)): the partial sums
+// and their fixed summation order - hence mean, rstd and every gradient - are bit-identical to running the G norms one by one.
+extern "C" size_t corrif_norm_workspace_g(int64_t rows_per_group, int32_t G, int32_t C) {
+    NormGeo n = norm_geo(rows_per_group, 1, C);
+    return (size_t)G * n.chunks * C * 2 * sizeof(double) + (size_t)G * C * 2 * sizeof(float) + 64;
+}
 
 // partial[((g*C + c)*chunks + chunk)*2 + {0,1}]
 template <int MODE>   // 0: sum x', sum x'^2 ; 1: sum g, sum g*xhat
@@ -283,14 +289,14 @@ static int run_ptrs(RunPtrs& r, float* const* rm, float* const* rv, int G) {
     return CORRIF_OK;
 }
 
-extern "C" int corrif_norm_stats_g(const float* x, int64_t ldx, int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, float eps,
-                                   float* mean, float* rstd, float* const* running_means, float* const* running_vars, float momentum,
-                                   double* ws, void* stream) {
+static int norm_stats_core(const float* x, int64_t ldx, int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, float eps,
+                           float* mean, float* rstd, float* const* running_means, float* const* running_vars, float momentum,
+                           double* ws, void* stream, int geoG) {
     if (!x || !mean || !rstd || !ws || !norm_args_ok(rows_per_group, G, C)) return CORRIF_EINVAL;
     if ((ldx & 3) || !al16(x)) return CORRIF_EUNSUPPORTED;
     RunPtrs run;
     if (run_ptrs(run, running_means, running_vars, G) != CORRIF_OK) return CORRIF_EINVAL;
-    NormGeo n = norm_geo(rows_per_group, G, C);
+    NormGeo n = norm_geo(rows_per_group, geoG, C);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL((norm_partial_kernel<0>), dim3(n.chunks, n.ctiles, G), dim3(256), 0, s, x, ldx, (const float*)nullptr, (int64_t)0,
                        (const float*)nullptr, (int64_t)0, (const float*)nullptr, (const float*)nullptr, ws, rows_per_group, (int)C,
@@ -301,12 +307,17 @@ extern "C" int corrif_norm_stats_g(const float* x, int64_t ldx, int64_t rows_per
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }
+extern "C" int corrif_norm_stats_g(const float* x, int64_t ldx, int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, float eps,
+                                   float* mean, float* rstd, float* const* running_means, float* const* running_vars, float momentum,
+                                   double* ws, void* stream) {
+    return norm_stats_core(x, ldx, rows_per_group, G, C, flags, eps, mean, rstd, running_means, running_vars, momentum, ws, stream, 1);
+}
 extern "C" int corrif_norm_stats(const float* x, int64_t ldx, int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, float eps,
                                  float* mean, float* rstd, float* running_mean, float* running_var, float momentum, double* ws,
                                  void* stream) {
     if (running_mean && (G != 1 || !running_var)) return CORRIF_EINVAL;
-    return corrif_norm_stats_g(x, ldx, rows_per_group, G, C, flags, eps, mean, rstd, running_mean ? &running_mean : nullptr,
-                               running_mean ? &running_var : nullptr, momentum, ws, stream);
+    return norm_stats_core(x, ldx, rows_per_group, G, C, flags, eps, mean, rstd, running_mean ? &running_mean : nullptr,
+                           running_mean ? &running_var : nullptr, momentum, ws, stream, G);
 }
 
 extern "C" int corrif_norm_stats_finalize_g(const double* part, int32_t chunks, int32_t G, int32_t C, int64_t rows_per_group, float eps,
@@ -354,10 +365,10 @@ extern "C" int corrif_norm_apply(const float* x, int64_t ldx, const float* mean,
     return corrif_norm_apply_g(x, ldx, mean, rstd, gamma, beta, residual, ldr, y, ldy, rows_per_group, G, C, flags, 0, stream);
 }
 
-extern "C" int corrif_norm_bwd_g(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
-                                 const float* mean, const float* rstd, const float* gamma, float* dx, int64_t lddx, float* dres,
-                                 int64_t lddres, float* dgamma, float* dbeta, int64_t rows_per_group, int32_t G, int32_t C,
-                                 int32_t flags, int32_t frozen, int64_t affine_gstride, double* ws, void* stream) {
+static int norm_bwd_core(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                         const float* mean, const float* rstd, const float* gamma, float* dx, int64_t lddx, float* dres,
+                         int64_t lddres, float* dgamma, float* dbeta, int64_t rows_per_group, int32_t G, int32_t C,
+                         int32_t flags, int32_t frozen, int64_t affine_gstride, double* ws, void* stream, int geoG) {
     if (!dy || !norm_args_ok(rows_per_group, G, C) || !ws) return CORRIF_EINVAL;
     if ((flags & CORRIF_NORM_RELU_OUT) && !y) return CORRIF_EINVAL;
     if (dx && (!x || !mean || !rstd)) return CORRIF_EINVAL;
@@ -366,7 +377,7 @@ extern "C" int corrif_norm_bwd_g(const float* dy, int64_t lddy, const float* y, 
         !al16(dres) || !al16(mean) || !al16(rstd) || !al16(gamma) || (affine_gstride & 3))
         return CORRIF_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    NormGeo n = norm_geo(rows_per_group, G, C);
+    NormGeo n = norm_geo(rows_per_group, geoG, C);
     // sums live behind the double partials in the same workspace
     float* sums = reinterpret_cast<float*>(ws + (size_t)G * n.chunks * C * 2);
     const bool need_sums = (!frozen && dx) || dgamma || dbeta;
@@ -387,12 +398,19 @@ extern "C" int corrif_norm_bwd_g(const float* dy, int64_t lddy, const float* y, 
     }
     return CORRIF_OK;
 }
+extern "C" int corrif_norm_bwd_g(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                                 const float* mean, const float* rstd, const float* gamma, float* dx, int64_t lddx, float* dres,
+                                 int64_t lddres, float* dgamma, float* dbeta, int64_t rows_per_group, int32_t G, int32_t C,
+                                 int32_t flags, int32_t frozen, int64_t affine_gstride, double* ws, void* stream) {
+    return norm_bwd_core(dy, lddy, y, ldy, x, ldx, mean, rstd, gamma, dx, lddx, dres, lddres, dgamma, dbeta, rows_per_group, G, C, flags, frozen,
+                         affine_gstride, ws, stream, 1);
+}
 extern "C" int corrif_norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
                                const float* mean, const float* rstd, const float* gamma, float* dx, int64_t lddx, float* dres,
                                int64_t lddres, float* dgamma, float* dbeta, int64_t rows_per_group, int32_t G, int32_t C,
                                int32_t flags, int32_t frozen, double* ws, void* stream) {
-    return corrif_norm_bwd_g(dy, lddy, y, ldy, x, ldx, mean, rstd, gamma, dx, lddx, dres, lddres, dgamma, dbeta, rows_per_group, G, C, flags,
-                             frozen, 0, ws, stream);
+    return norm_bwd_core(dy, lddy, y, ldy, x, ldx, mean, rstd, gamma, dx, lddx, dres, lddres, dgamma, dbeta, rows_per_group, G, C, flags,
+                         frozen, 0, ws, stream, G);
 }
 
 extern "C" int corrif_norm_bwd_pre_g(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx, const float* mean,
@@ -433,7 +451,7 @@ extern "C" size_t corrif_col_sum_workspace(int64_t rows, int32_t C) { return cor
 extern "C" int corrif_col_sum_g(const float* x, int64_t ld, int64_t rows, int32_t G, int32_t C, float* out, double* ws, void* stream) {
     if (!x || !out || !ws || !norm_args_ok(rows, G, C)) return CORRIF_EINVAL;
     if ((ld & 3) || !al16(x)) return CORRIF_EUNSUPPORTED;
-    NormGeo n = norm_geo(rows, G, C);
+    NormGeo n = norm_geo(rows, 1, C);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL((norm_partial_kernel<0>), dim3(n.chunks, n.ctiles, G), dim3(256), 0, s, x, ld, (const float*)nullptr, (int64_t)0,
                        (const float*)nullptr, (int64_t)0, (const float*)nullptr, (const float*)nullptr, ws, rows, (int)C, 0, n);

@@ -8,15 +8,22 @@ gradients are averaged across ranks.
 Design for xGMI (point-to-point links, ring collectives are per-link bound): few large buckets (default 64 MB) issued in
 reverse-forward order from autograd post-accumulate hooks on a side stream, so the all-reduce of the decoder's gradients
 overlaps the encoders' backward; the parameters that never receive a gradient (the model names them: `NOGRAD_PREFIXES`,
-18 tensors for MMVit4) are never communicated; gradients live as views of the flat buckets so no flatten/unflatten copies
-are made.  Buckets exist before the first backward (the grad-less set is known from the model), so step 1 overlaps like
-every other step; collectives are issued strictly in bucket-index order on every rank (a bucket that completes early waits
-for its predecessors), so the order never depends on the autograd engine's scheduling; the 1/world averaging runs on the
-communication stream right behind each all-reduce (own kernel, no ATen launch).
+18 tensors for MMVit4) are never communicated.
+
+The backward pass itself is the SAME as on one GPU (round 3): `zero_grad()` drops the gradients, the kernels write ordinary gradient
+tensors that autograd adopts (no accumulation launches, side-stream weight gradients stay enabled), and a bucket is assembled when its
+last gradient exists - ONE multi-tensor gather launch per bucket (corrif_gather_multi) on the communication stream, then the all-reduce,
+then the 1/world averaging; `finish()` re-points every `p.grad` at its slice of the reduced bucket (no unflatten copy).  Rounds 1-2 kept
+the gradients as bucket views instead: one stock ATen `add_` per parameter and step, a 341 MB zero fill and one event per parameter.
+Buckets exist before the first backward (the grad-less set is known from the model), so step 1 overlaps like every other step;
+collectives are issued strictly in bucket-index order on every rank (a bucket that completes early waits for its predecessors), so
+the order never depends on the autograd engine's scheduling.
 
 BatchNorm buffers (running statistics, counters) stay per rank during training; `sync_buffers` / `save_checkpoint`
 implement the SURVEY section 8(e) policy: rank 0's buffers are broadcast before a checkpoint is written, and rank 0 writes it.
 """
+import struct
+
 import torch
 import torch.distributed as dist
 
@@ -27,14 +34,6 @@ def _scale_(flat, alpha):
         H.check(H.lib().corrif_scale(flat.data_ptr(), flat.data_ptr(), flat.numel(), alpha, H.stream()), "corrif_scale")
     else:                                  # gloo rehearsal on CPU tensors (tests): host arithmetic
         flat.mul_(alpha)
-
-
-def _zero_(flat):
-    if flat.is_cuda:
-        import corrif_hip as H
-        H.check(H.lib().corrif_fill(flat.data_ptr(), flat.numel(), 0.0, H.stream()), "corrif_fill")
-    else:
-        flat.zero_()
 
 
 class GradAllReducer:
@@ -54,10 +53,10 @@ class GradAllReducer:
         self._stream = None
         self._next = 0
         if not self.active:
-            # one rank, no collective to run: no buckets at all.  zero_grad() drops the gradients (p.grad = None), so autograd's
-            # AccumulateGrad adopts each freshly produced gradient tensor instead of adding it into a zeroed bucket view - that add was
-            # one stock ATen launch per parameter and step (645 of them in the single-GPU step of round 1).
-            return
+            return                           # one rank, no collective: zero_grad() / finish() are all that is left of this class
+        if self.world > 1 and self.params and self.params[0].is_cuda:
+            import ops
+            ops.follow_torch_seed(dist.get_rank(process_group))      # ranks that call the same torch.manual_seed() still draw their own dropout masks
         if skip_prefixes is not None:        # the grad-less set is known: buckets (and hooks) exist before the first backward
             self._build([p for n, p in named if not n.startswith(tuple(skip_prefixes))])
         # else: built lazily after the first backward, from the parameters that did receive a gradient
@@ -86,25 +85,69 @@ class GradAllReducer:
 
     def _make_bucket(self, params):
         n = sum(p.numel() for p in params)
-        flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
-        o = 0
+        dev = params[0].device
+        flat = torch.empty(n, dtype=params[0].dtype, device=dev)
+        offs, o = [], 0
         for p in params:
-            v = flat[o:o + p.numel()].view_as(p)
-            if p.grad is not None:
-                v.copy_(p.grad)
-            p.grad = v               # gradient now lives inside the bucket (autograd accumulates in place)
+            offs.append(o)
             o += p.numel()
-        return {"params": params, "flat": flat, "ready": 0, "work": None, "events": [], "launched": False}
+        b = {"params": params, "flat": flat, "offs": offs, "ready": 0, "work": None, "streams": {}, "launched": False, "scaled": False}
+        if flat.is_cuda:
+            # block lists of the one-launch gather (which 1024-element block copies which tensor): fixed per bucket; the 24-byte
+            # (src, offset, n) records are refreshed every step through a pinned staging buffer (gradient tensors are new each step)
+            bt, bo = [], []
+            for ti, p in enumerate(params):
+                nb = (p.numel() + 1023) // 1024
+                bt.append(torch.full((nb,), ti, dtype=torch.int32))
+                bo.append(torch.arange(nb, dtype=torch.int64) * 1024)
+            b["bt"], b["bo"] = torch.cat(bt).to(dev), torch.cat(bo).to(dev)
+            b["host"] = [torch.empty(24 * len(params), dtype=torch.uint8).pin_memory() for _ in range(2)]
+            b["host_ev"], b["flip"] = [None, None], 0
+            b["table"] = torch.empty(24 * len(params), dtype=torch.uint8, device=dev)
+        return b
+
+    def _gather(self, b):
+        """flat <- the bucket's gradients (a parameter without one contributes zeros), on the current stream"""
+        flat = b["flat"]
+        if not flat.is_cuda:
+            for p, o in zip(b["params"], b["offs"]):
+                seg = flat[o:o + p.numel()]
+                if p.grad is None:
+                    seg.zero_()
+                else:
+                    seg.copy_(p.grad.reshape(-1))
+            return
+        import corrif_hip as H
+        raw = bytearray()
+        keep = []
+        for p, o in zip(b["params"], b["offs"]):
+            g = p.grad
+            if g is not None and not g.is_contiguous():
+                g = g.contiguous()
+            keep.append(g)
+            raw += struct.pack("<Qqq", 0 if g is None else g.data_ptr(), o, p.numel())
+        k = b["flip"] = b["flip"] ^ 1
+        if b["host_ev"][k] is not None:
+            b["host_ev"][k].synchronize()        # the copy that last read this staging buffer (two steps ago) has completed
+        b["host"][k].copy_(torch.frombuffer(raw, dtype=torch.uint8))
+        b["table"].copy_(b["host"][k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        b["host_ev"][k] = ev
+        H.check(H.lib().corrif_gather_multi(b["table"].data_ptr(), b["bt"].data_ptr(), b["bo"].data_ptr(), b["bt"].numel(), flat.data_ptr(),
+                                            H.stream()), "corrif_gather_multi")
+        for g in keep:                           # the gradient tensors are read on this (communication) stream
+            if g is not None:
+                g.record_stream(torch.cuda.current_stream())
 
     # ---------------------------------------------------------------- hooks / reduction
     def _on_grad(self, p):
         """post-accumulate hook (only installed when collectives will run): count the bucket's parameters; remember on which
-        stream each gradient was produced (the model runs its modality branches / sample-group lanes on several streams)"""
+        streams its gradients became final (the model runs its modality branches / sample-group lanes on several streams)"""
         b = self.buckets[self._index[p]]
         b["ready"] += 1
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        b["events"].append(ev)
+        st = torch.cuda.current_stream()
+        b["streams"][st.cuda_stream] = st
         self._launch_ready()
 
     def _launch_ready(self):
@@ -118,42 +161,47 @@ class GradAllReducer:
 
     def _launch(self, b):
         b["launched"] = True
-        if not self.active:
-            b["events"] = []
-            return
         alpha = 1.0 / self.world
         if self._stream is not None:
-            self._stream.wait_stream(torch.cuda.current_stream())
-            for ev in b["events"]:
-                self._stream.wait_event(ev)
-            b["events"] = []
-            with torch.cuda.stream(self._stream):
+            comm = self._stream
+            comm.wait_stream(torch.cuda.current_stream())
+            for st in b["streams"].values():     # one wait per DISTINCT producer stream (rounds 1-2: one event per parameter)
+                comm.wait_stream(st)
+            try:
+                import ops
+                for ent in ops._side_streams.values():      # weight gradients enqueued on side streams (ops.SIDE_WGRAD*)
+                    comm.wait_stream(ent[0])
+            except ImportError:
+                pass
+            b["streams"] = {}
+            with torch.cuda.stream(comm):
+                self._gather(b)
                 b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 if self.world > 1:
                     b["work"].wait()             # stream-level dependency only (does not block the host for RCCL)
                     _scale_(b["flat"], alpha)    # average on the communication stream, behind the collective
                     b["scaled"] = True
         else:
+            self._gather(b)
             b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def zero_grad(self):
-        """keeps the bucket views alive (set_to_none would drop them)"""
+        """drops the gradients (like torch.optim's set_to_none): the next backward's kernels write fresh tensors that autograd adopts"""
+        for p in self.params:
+            p.grad = None
         if self.buckets is None or not self.active:
-            for p in self.params:
-                p.grad = None
             return
         for b in self.buckets:
-            _zero_(b["flat"])
             b["ready"] = 0
             b["work"] = None
-            b["events"] = []
+            b["streams"] = {}
             b["launched"] = False
             b["scaled"] = False
         self._next = 0
 
     def finish(self):
         """call after backward(): issues whatever the hooks have not issued (in index order), waits, averages.  After it returns
-        every rank holds the mean gradient in p.grad."""
+        every rank holds the mean gradient in p.grad (a view of its bucket)."""
         if not self.active:
             return
         if self.buckets is None:
@@ -172,6 +220,9 @@ class GradAllReducer:
             b["ready"] = 0
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
+        for b in self.buckets:           # the reduced gradient of every parameter is its slice of the bucket: no copy back
+            for p, o in zip(b["params"], b["offs"]):
+                p.grad = b["flat"][o:o + p.numel()].view_as(p)
 
     def communicated_elements(self):
         return 0 if self.buckets is None else sum(b["flat"].numel() for b in self.buckets)

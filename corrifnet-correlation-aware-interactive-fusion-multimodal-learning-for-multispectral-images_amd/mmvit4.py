@@ -526,8 +526,11 @@ class Decoder_fuse(nn.Module):
                 parts_s[l] = skip_branch(l)
             if fs[l]:
                 ys, w_y = parts_s[l]
-                yc = ops.conv3d(part_y, w_y, c2.conv.bias, c2.conv.stride, c2.conv.pad, c2.conv.replicate)
-                y = cout(c2.norm(ops.depth_bcast_add(yc, ys)))
+                # the skip channels' share is broadcast-added by depth class in the convolution's epilogue, which then also takes the
+                # InstanceNorm statistics of the sum (no depth_bcast_add pass, no statistics pass over the 64^3 / 128^3 tensors)
+                hb, st = {"ys": ys, "done": False}, {"G": part_y.shape[0], "relu": True, "after_bcast": True}
+                yc = ops.conv3d(part_y, w_y, c2.conv.bias, c2.conv.stride, c2.conv.pad, c2.conv.replicate, stats=st, bcast=hb)
+                y = cout(c2.norm(ops.depth_bcast_add(yc, ys, fused=hb["done"]), pre=st))
             else:
                 y = cout(c2(ops.cat_channels(cat, parts_s[l], part_y)))
         up = ops.trilinear(y, (1, 224, 224))                                   # up_to_224 (mmvit4.py:263): depth slice 0 only
@@ -652,10 +655,14 @@ class MMVit4(nn.Module):
         # inter-modal correlation: run them on three HIP streams so that their small late-stage launches (e4/e5: 1-2
         # workgroups per CU each) fill the 256 CUs together.  Same kernels, same order per branch: results are unchanged.
         self.concurrent_branches = True
-        # The three encoders are the SAME network on three inputs (mmvit4.py:442-447): their twin layers run as ONE grouped launch each
-        # (stacked activations, stacked weights; _encoders_grouped) - 3x fewer, 3x larger launches whose tile grids fill the chip more
-        # evenly than three small ones.  False = one Encoder.forward per modality (the three-stream schedule of rounds 1-2).
-        self.grouped_encoders = True
+        # The three encoders are the SAME network on three inputs (mmvit4.py:442-447): their twin layers can run as ONE grouped launch
+        # each (stacked activations, stacked weights; _encoders_grouped) - 3x fewer, 3x larger launches whose tile grids fill the chip
+        # more evenly than three small ones (encoder GEMMs +10-25 % in isolation).  The price is the overlap of one branch's HBM-bound
+        # BatchNorm passes with another branch's matrix work, which only the three-stream schedule has.  Measured (round 3, fwd+bwd,
+        # 4 bands 224^2, ms per step grouped / per modality): B=32 259 / 247, B=16 135 / 129, B=8 75.0 / 73.4, B=4 45.7 / 62.2,
+        # B=2 44.0 / 58.5.  None = choose per call (encoders_grouped_for): grouped when the step is launch-bound (small batches) or the
+        # schedule is single-stream anyway (near the HBM capacity, CORRIF_SERIAL), per modality otherwise; True / False force one.
+        self.grouped_encoders = None
         self._gcache = None
         self.interleave_branches = True      # enqueue the three branches layer by layer in turn (diagnostics / A-B: False = branch after branch)
         self._streams = None
@@ -735,6 +742,16 @@ class MMVit4(nn.Module):
             torch.cuda.reset_peak_memory_stats(dev)
         return plan[0]
 
+    def encoders_grouped_for(self, x):
+        """the encoder schedule `forward` uses for input x under the current switches (see __init__)"""
+        if self.grouped_encoders is not None:
+            return bool(self.grouped_encoders)
+        if not self.concurrent_branches:
+            return True                        # one stream: nothing to overlap, the larger launches are a pure gain
+        B, _, D, Hh, W = x.shape
+        rows_e4 = B * D * ((Hh + 15) // 16) * ((W + 15) // 16)          # GEMM rows of one modality at the e4 level
+        return rows_e4 < 5000                  # B <= 6 at 4 bands 224^2: one modality's launches leave most of the 256 CUs idle
+
     def _encoders_grouped(self, x, cats):
         """The three modality encoders as one stacked pass.  Returns (cat[0..5], tok): the six early-fusion concat buffers as autograd
         tensors (the grouped adapt / conv6 convolutions write every modality's channel slice in one launch) and the encode_conv tokens
@@ -794,7 +811,7 @@ class MMVit4(nn.Module):
         cats.append(torch.empty((B, P3, P3, P3, num_modals * basic_dims * 8), dtype=torch.float32, device=x.device))
         feats, skip, qkv = [None] * 3, [None] * 3, [None] * 3
         catf = None
-        if self.grouped_encoders:
+        if self.encoders_grouped_for(x):
             catf, tok_all = self._encoders_grouped(x, cats)
             toks = ops.split_batch(tok_all, [B * k for k in range(num_modals + 1)])
 

@@ -66,6 +66,12 @@ STREAM_K_LONG = False     # measured (round 2): wall-neutral on the B=32 step (2
 # Grouped launches (Z = 3 twin layers of the modality encoders) with a long K loop: the split pays (tools/group_microbench.py, round 3: e4 conv2
 # 99 -> 106 TFLOP/s, e5 conv2 85 -> 108, e5 conv1 92 -> 102) while short-K shapes lose 8-9 % to the slab round trip (K <= 1024).
 STREAM_K_GROUPED = True
+# Two-level K accumulation of the forward / data-gradient GEMMs (CorrifGemm.no_ksplit = 0): a fresh fma chain every 512 products.  One
+# chain over all of K has 1.9x (K = 1024) ... 4.5x (K = 4608-8640) ATen's local error against fp64 (tools/local_error.py; oneDNN
+# accumulates in blocks), with it the kernels sit at ATen's level - at 7-9 % of the long-K launches' time (the second accumulator set
+# costs a wave of occupancy; tools/group_microbench.py), 1.7 % of the step.  Both are 4x inside the per-kernel bar (2e-6 forward) and the
+# end-to-end brackets do not move (tools/grad_diag.py: median gradient-error ratio 0.94 vs 0.95), so the default is the fast one.
+K_SPLIT_ACCUM = False
 
 
 def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, addend=None, ld_add=0, act=ACT_NONE,
@@ -102,6 +108,7 @@ def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, add
     buf = None
     sk = STREAM_K or (STREAM_K_LONG and K >= 2048 and Z == 1 and M * N <= 128 * 128 * 512) or (STREAM_K_GROUPED and zs is not None and K >= 2048)
     g.no_split = 0 if sk else 1
+    g.no_ksplit = 0 if K_SPLIT_ACCUM else 1
     if sk:
         nws = lib().corrif_gemm_fwd_workspace(g)      # stream-K split: slabs for the tiles a share boundary cuts
         if nws:
@@ -161,9 +168,15 @@ def repack(src, shape_out, O, I, T, mode, ldo, zero=False):
     return out
 
 
-def conv3_patch(x, ldx, wp, y, ldy, bias, B, S, O, Ci, Co, pad, clamp, cc, fold=False):
+def conv3_patch(x, ldx, wp, y, ldy, bias, B, S, O, Ci, Co, pad, clamp, cc, fold=False, stats=None, add=None):
+    """stats: (partials pointer, chunks, relu) - InstanceNorm statistics of the output from the epilogue; add: (pointer, row pitch, Ds) -
+    the compact skip branch's share broadcast-added by depth class in the epilogue (CorrifConv3Patch.stats_part / add_src)"""
     q = H.Conv3Patch()
     q.fold = 1 if fold else 0
+    if stats is not None:
+        q.stats_part, q.stats_chunks, q.stats_relu = stats
+    if add is not None:
+        q.add_src, q.ld_add, q.add_Ds = add
     q.X, q.ldx, q.Wp, q.Y, q.ldy = x, ldx, wp, y, ldy
     q.bias = bias
     q.B = B
@@ -197,6 +210,7 @@ def stem_wgrad(x, batch_pitch, gy, ldg, gwp, B, D, Hh, W):
 
 
 USE_PATCH = True      # diagnostics: False routes the narrow 3x3x3 layers through the implicit-GEMM kernels instead of the patch kernels
+PATCH_STATS = True    # diagnostics / A-B: False = the InstanceNorm after a patch-kernel convolution takes its statistics in its own pass
 
 
 def _patch_cc(k, stride, pad, Ci, Co):
@@ -331,7 +345,7 @@ class ConvFn(Function):
     """nn.Conv3d on channels-last activations.  weight stays in the reference (O,I,kd,kh,kw) layout."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, replicate, out, act, stats_req, grad_link=None, side_ok=False, bwd_stats=None):
+    def forward(ctx, x, weight, bias, stride, pad, replicate, out, act, stats_req, grad_link=None, side_ok=False, bwd_stats=None, bcast=None):
         ctx.grad_link = grad_link
         ctx.side_ok = side_ok
         ctx.bwd_stats = bwd_stats
@@ -369,7 +383,20 @@ class ConvFn(Function):
         elif _patch_cc((kd, kh, kw), stride, pad, Ci, Co) and act == ACT_NONE:
             cc = _patch_cc((kd, kh, kw), stride, pad, Ci, Co)
             wp = repack(weight, (Ci // cc, Co, T, cc), Co, Ci, T, 3, cc)
-            conv3_patch(P(x), lda, P(wp), P(y), ldc, P(bias), B, (Di, Hi, Wi), (Do, Ho, Wo), Ci, Co, 1, replicate, cc)
+            add = pst = None
+            if bcast is not None:                     # the compact skip branch's share of d*_c2, added by depth class in the epilogue
+                bv, _, ldb = rows_view(bcast["ys"])
+                assert bv is bcast["ys"] and tuple(bv.shape) == (B, bv.shape[1], Ho, Wo, Co) and bv.shape[1] % 3 == 0
+                add = (P(bv), ldb, bv.shape[1] // 3)
+                bcast["done"] = True
+            if PATCH_STATS and stats_req is not None and stats_req["G"] == B and stats_req["relu"] and \
+                    lib().corrif_conv3_patch_stats_supported(Ci, Co):
+                chunks = lib().corrif_conv3_patch_stats_chunks(B, Do, Ho, Wo)      # InstanceNorm statistics partials from the epilogue
+                part = torch.empty(B * Co * chunks * 2, dtype=torch.float64, device=x.device)
+                check(lib().corrif_fill(P(part), 2 * part.numel(), 0.0, stream()), "corrif_fill")
+                pst = (part.data_ptr(), chunks, 1)
+                stats_req["part"], stats_req["chunks"], stats_req["rpg"] = part, chunks, Do * Ho * Wo
+            conv3_patch(P(x), lda, P(wp), P(y), ldc, P(bias), B, (Di, Hi, Wi), (Do, Ho, Wo), Ci, Co, 1, replicate, cc, stats=pst, add=add)
         else:
             wp = weight if T == 1 else repack(weight, (Co, T * Ci), Co, Ci, T, 0, T * Ci)
             geom = H.gemm_geom() if is_gemm else H.conv_geom((Do, Ho, Wo), (Di, Hi, Wi), (kd, kh, kw), stride, pad, clamp=replicate)
@@ -455,14 +482,14 @@ class ConvFn(Function):
             ws = _ws(lib().corrif_conv1x1_small_workspace(M, Ci, Co), dev)
             check(lib().corrif_conv1x1_small_wgrad(P(x), lda, P(gy), ldg, P(gw), P(gb), P(ws), M, Ci, Co, stream()), "corrif_conv1x1_small_wgrad")
             gx = _finish_link(ctx.grad_link, gx)
-            return gx, gw, gb, None, None, None, None, None, None, None, None, None
+            return gx, gw, gb, None, None, None, None, None, None, None, None, None, None
         side = None
         if SIDE_WGRAD and ctx.side_ok and ctx.needs_input_grad[1] and weight.grad is None and not torch.cuda.is_current_stream_capturing():
             side = _side_begin((gy, x))
         with torch.cuda.stream(side) if side is not None else _NullCtx():
             gw, gb = ConvFn._weight_grads(ctx, x, weight, gy, M, ldg, dev)
         gx = _finish_link(ctx.grad_link, gx)
-        return gx, gw, gb, None, None, None, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None, None, None
 
     @staticmethod
     def _weight_grads(ctx, x, weight, gy, M, ldg, dev):
@@ -540,10 +567,14 @@ def grad_tap(x, link):
 
 
 def conv3d(x, weight, bias=None, stride=(1, 1, 1), pad=(0, 0, 0), replicate=False, out=None, act=ACT_NONE, stats=None, grad_link=None,
-           side_wgrad=False, bwd_stats=None):
+           side_wgrad=False, bwd_stats=None, bcast=None):
     """stats: None, or a dict {"G": groups, "relu": bool}: ask the GEMM epilogue for the statistics partials of the norm that follows;
     on success the dict gains "part" / "chunks" / "rpg" (pass it to batch_norm / relu_instnorm as `pre`)."""
-    return ConvFn.apply(x, weight, bias, tuple(stride), tuple(pad), bool(replicate), out, act, stats, grad_link, bool(side_wgrad), bwd_stats)
+    if bcast is not None and not (_patch_cc(tuple(weight.shape[2:]), tuple(stride), tuple(pad), weight.shape[1], weight.shape[0]) and act == ACT_NONE):
+        bcast = None              # only the patch kernel's epilogue can absorb the depth-class add (bcast["done"] stays False: the caller adds)
+    if bcast is None and stats is not None and stats.get("after_bcast"):
+        stats = None              # the statistics must see the sum: without the fused add they are taken by the norm's own pass
+    return ConvFn.apply(x, weight, bias, tuple(stride), tuple(pad), bool(replicate), out, act, stats, grad_link, bool(side_wgrad), bwd_stats, bcast)
 
 
 class SplitWeightFn(Function):
@@ -587,13 +618,15 @@ class DepthBcastAddFn(Function):
     through to y and is class-reduced for ys."""
 
     @staticmethod
-    def forward(ctx, y, ys):
+    def forward(ctx, y, ys, fused=False):
+        """fused: the convolution that produced y already added ys in its epilogue (CorrifConv3Patch.add_src): autograd wiring only"""
         B, D, Hh, W, C = y.shape
         yv, _, ldy = rows_view(y)
         sv, _, lds = rows_view(ys)
         Ds = ys.shape[1] // 3
         assert yv is y and tuple(ys.shape) == (B, 3 * Ds, Hh, W, C) and D >= 2 * Ds
-        check(lib().corrif_depth_bcast_add(P(y), ldy, P(sv), lds, B, D, Hh * W, C, Ds, stream()), "corrif_depth_bcast_add")
+        if not fused:
+            check(lib().corrif_depth_bcast_add(P(y), ldy, P(sv), lds, B, D, Hh * W, C, Ds, stream()), "corrif_depth_bcast_add")
         ctx.mark_dirty(y)
         ctx.cfg = (Ds, tuple(ys.shape))
         return y
@@ -605,11 +638,11 @@ class DepthBcastAddFn(Function):
         gv, _, ldg = rows_view(g)
         gs = torch.empty(sshape, dtype=torch.float32, device=g.device)
         check(lib().corrif_depth_class_reduce(P(gv), ldg, P(gs), C, B, D, Hh * W, C, Ds, stream()), "corrif_depth_class_reduce")
-        return g, gs
+        return g, gs, None
 
 
-def depth_bcast_add(y, ys):
-    return DepthBcastAddFn.apply(y, ys)
+def depth_bcast_add(y, ys, fused=False):
+    return DepthBcastAddFn.apply(y, ys, bool(fused))
 
 
 # --------------------------------------------------------------------------------------- grouped (stacked-modality) operators
@@ -805,7 +838,7 @@ class GroupedBatchNormFn(Function):
                 check(lib().corrif_norm_stats_finalize_g(P(pre["part"]), pre["chunks"], G, C, rpg, eps, P(mean), P(rstd), rm, rv, momentum,
                                                          stream()), "corrif_norm_stats_finalize_g")
             else:
-                ws = _norm_ws(rpg, G, C, dev)
+                ws = _ws(lib().corrif_norm_workspace_g(rpg, G, C), dev)
                 check(lib().corrif_norm_stats_g(P(x), ldx, rpg, G, C, flags, eps, P(mean), P(rstd), rm, rv, momentum, P(ws), stream()),
                       "corrif_norm_stats_g")
         else:
@@ -853,7 +886,7 @@ class GroupedBatchNormFn(Function):
                   "corrif_norm_bwd_pre_g")
             NORM_BWD_STATS["epilogue"] += G
         else:
-            ws = _norm_ws(rpg, G, C, dev)
+            ws = _ws(lib().corrif_norm_workspace_g(rpg, G, C), dev)
             check(lib().corrif_norm_bwd_g(P(gy), ldg, P(y), ldy, P(x), ldx, P(mean), P(rstd), P(gamma), P(gx), C, P(gres), C, P(ggamma),
                                           P(gbeta), rpg, G, C, flags, 1 if frozen else 0, C, P(ws), stream()), "corrif_norm_bwd_g")
             NORM_BWD_STATS["pass"] += G

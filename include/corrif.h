@@ -118,6 +118,9 @@ typedef struct CorrifGemm {
      * per outer batch index (floats; zs_stats in doubles): bias, addend, addend2, stats_part, bstats_x, bstats_y, bstats_mean / _rstd.
      * With Z > 1 the fused statistics are per group: stats_rows_per_group must equal M. */
     int64_t zs_bias, zs_add, zs_add2, zs_stats, zs_bsx, zs_bsy, zs_bsstat;
+    /* K >= 1024 accumulates in two levels (a fresh fma chain every 512 products, folded into a second accumulator set): one chain over all
+     * of K loses accuracy like sqrt(K) (3-4x ATen's error at K = 4608, tools/local_error.py).  no_ksplit = 1 restores the single chain (A/B). */
+    int32_t no_ksplit;
 } CorrifGemm;
 int corrif_gemm_fwd(const CorrifGemm* p, void* stream);
 size_t corrif_gemm_fwd_workspace(const CorrifGemm* p);   /* bytes of CorrifGemm.ws this launch needs; queries the device's CU count */
@@ -183,8 +186,20 @@ typedef struct CorrifConv3Patch {
     int32_t B, Sd, Sh, Sw, Od, Oh, Ow, Ci, Co, pad, clamp, cc;
     int32_t fold;                    /* 1: data gradient of a replicate-padded conv with the padding adjoint fused: O = (n+2)^3 padded grid,
                                       * pad = 2, Y = the n^3 input gradient (rows of the n grid); needs n_d % 4 == n_h % 4 == n_w % 16 == 0 */
+    /* forward epilogue extras (ABI 6; general_conv3d_prenorm, mmvit4.py:41-45: conv -> ReLU -> InstanceNorm3d):
+     *   stats_part != NULL: per (sample, channel) sum and sum of squares of the stored values (after max(., 0) when stats_relu) into
+     *     stats_part[((b*Co + c)*stats_chunks + slot)*2 + {0,1}] (doubles, PRE-ZEROED by the caller, stats_chunks =
+     *     corrif_conv3_patch_stats_chunks(...)); corrif_norm_stats_finalize(stats_part, stats_chunks, B, Co, Od*Oh*Ow, ...) turns them
+     *     into mean / rstd - the separate statistics pass over the conv output disappears;
+     *   add_src != NULL: Y[b,d,h,w,:] += add_src[b, cls(d), h, w, :] with the depth classes of corrif_depth_bcast_add (add_Ds source
+     *     slices, add_src on the 3*add_Ds grid, row pitch ld_add) before the statistics - the compact skip branch's share of d*_c2
+     *     (mmvit4.py:271-287) without its own pass over the full-depth tensor. */
+    double* stats_part; int32_t stats_chunks, stats_relu;
+    const float* add_src; int64_t ld_add; int32_t add_Ds;
 } CorrifConv3Patch;
 int corrif_conv3_patch(const CorrifConv3Patch* p, void* stream);
+int corrif_conv3_patch_stats_chunks(int32_t B, int32_t Od, int32_t Oh, int32_t Ow);   /* host-only */
+int corrif_conv3_patch_stats_supported(int32_t Ci, int32_t Co);                       /* host-only: Co = 8, or Co = 16 with 8-channel chunks */
 int corrif_conv3_patch_cc(int32_t Ci, int32_t Co);     /* host-only */
 /* weight gradient of the same layers (Cout <= 16, Cin % 16 == 0): dW[Co][27][Ci] (then corrif_weight_repack mode 2).
  * X is the layer input (S grid), DY the output gradient (O grid = S grid, pad 1), ws = corrif_conv3_patch_wgrad_workspace bytes. */
@@ -256,6 +271,8 @@ size_t corrif_norm_workspace(int64_t rows_per_group, int32_t G, int32_t C);
  * x[:,2]): group g = modality g, rows_per_group rows each, its own nn.BatchNorm3d.  affine_gstride = C: gamma / beta / dgamma / dbeta are
  * [G][C] (one parameter set per group); 0: shared [C] as in the plain entries.  running_means / running_vars: host arrays of G (<= 4)
  * device pointers, one per group's module buffers, or NULL. */
+size_t corrif_norm_workspace_g(int64_t rows_per_group, int32_t G, int32_t C);   /* ws of corrif_norm_stats_g / _bwd_g / corrif_col_sum_g: every group is
+                                                                                  * chunked like a standalone G = 1 launch (bit-identical results) */
 int corrif_norm_stats_g(const float* x, int64_t ldx, int64_t rows_per_group, int32_t G, int32_t C, int32_t flags, float eps, float* mean,
                         float* rstd, float* const* running_means, float* const* running_vars, float momentum, double* ws, void* stream);
 int corrif_norm_stats_finalize_g(const double* part, int32_t chunks, int32_t G, int32_t C, int64_t rows_per_group, float eps, float* mean,
@@ -276,6 +293,10 @@ int corrif_col_sum_g(const float* x, int64_t ld, int64_t rows, int32_t G, int32_
 /* dst[g][0..n) = srcs[g][0..n): the weights / affine parameters of G (<= 4) same-shaped modules (the three modality encoders' twin
  * layers, mmvit4.py:394-396) gathered into one stacked operand of a grouped launch; srcs = host array of G device pointers */
 int corrif_stack_groups(const float* const* srcs, int32_t G, float* dst, int64_t n, void* stream);
+/* dst[entry.dst_off + i] = entry.src[i] (0 when src is NULL) for every entry of `table` ({const float* src; int64_t dst_off; int64_t n}
+ * records in device memory) in ONE launch: block b handles elements [blk_off[b], blk_off[b] + 1024) of tensor blk_tensor[b].  Assembles
+ * a gradient all-reduce bucket from the parameter gradients the backward kernels produced (data-parallel layer). */
+int corrif_gather_multi(const void* table, const int32_t* blk_tensor, const int64_t* blk_off, int32_t nblocks, float* dst, void* stream);
 
 /* LayerNorm over the last dim (C = 512), eps 1e-5 (mmvit4.py:327,335; aten::native_layer_norm).
  * Optional fused pre-add: xin = x + pos[row % pos_rows] (Transformer.forward `x = x + pos`,

@@ -188,16 +188,17 @@ def test_stage_taps_against_reference_fixture(name):
 
 def test_full_gradient_against_oracle():
     """EVERY parameter gradient (not a sample) and every buffer against the CPU oracle on the same inputs.
-    Bracketed: the oracle is run in fp64 (truth) and fp32 (= the reference's arithmetic, bit-identical to it on CPU);
-    per parameter the HIP path's rel-L2 error vs fp64 is compared with the fp32 oracle's own error (floor 2e-4).  The two are independent
-    rounding realisations of the same arithmetic and the ratio is heavy-tailed for gradients that cancel analytically (biases in front of
-    a normalisation: the oracle's own error is 1e-2 there), so the bar is statistical: no tensor beyond 8x, at most 1 % of the 645 tensors
-    beyond 4x, and the MEDIAN ratio <= 2.  The median is itself realisation-dependent, because every gradient inherits the same upstream
-    rounding noise: two equally accurate stem kernels (scalar-gather GEMM / patch-staged, both 2e-6 against F.conv3d) give 1.39 and 1.53
-    on this case, other weight seeds 1.16-1.58 (tools/grad_diag.py); a kernel family that lost accuracy systematically would show
-    ratios of 10+ on its own tensors and trip the 4x / 8x counts.  64^2 input at batch 2: e4 / e5 still see 4x4 and
-    2x2 maps (96 / 24 samples per BatchNorm channel); at 32^2 (round 1) e5 normalised over 3 samples and both the oracle's fp32 error
-    and ours were O(1) there, which tested nothing."""
+    Bracketed: the oracle is run in fp64 (truth) and fp32 (= the reference's arithmetic, bit-identical to it on CPU); per parameter the
+    HIP path's rel-L2 error vs fp64 must stay within 4 x the fp32 oracle's own error (floor 2e-4), and the MEDIAN ratio over the 645
+    tensors within 1.5 (round 1's bar; round 2 had loosened it to 2.0 / a 1 % quota beyond 4x when this case measured 1.39-1.58).
+    Round 3 located what moves that number: (i) per LAYER, against fp64 on identical inputs, every kernel family is
+    at ATen's local error except the forward / data-gradient GEMMs with a long K loop - one fp32 fma chain over all of K: 1.9x at
+    K = 1024 ... 4.5x at K = 4608-8640, tools/local_error.py; ops.K_SPLIT_ACCUM removes it at 1.7 % of the step and is off by default;
+    (ii) end to end the ratio is dominated by WHICH rounding realisation the network's ~50x amplification happens to see: the same
+    case gives 0.94 with the compact skip branch now also taken at 3 bands and grouped encoder launches, 0.95 with the two-level
+    accumulation off, 0.99 with per-modality encoders (tools/grad_diag.py 2 3 64 1.0 11).  64^2 input at batch 2: e4 / e5 still see
+    4x4 and 2x2 maps (96 / 24 samples per BatchNorm channel); at 32^2 (round 1) e5 normalised over 3 samples and both the oracle's
+    fp32 error and ours were O(1) there, which tested nothing."""
     from oracle import mmvit4_oracle as O
     case = dict(B=2, D=3, H=64, W=64, mode="train_nodrop", conv_gain=1.0, wseed=11)
     model, pred, mask, loss, sd = run_hip(case)
@@ -227,10 +228,13 @@ def test_full_gradient_against_oracle():
         e_hip = ((p.grad.cpu().double() - g64[k]).norm() / nrm).item()
         e_ref = ((g32[k] - g64[k]).norm() / nrm).item()
         ratios.append(e_hip / max(e_ref, 1e-6))
-        if e_hip > max(4 * e_ref, 2e-4):
+        # biases of a conv -> ReLU -> InstanceNorm block: the normalisation annihilates their gradient except through the ReLU pattern, the
+        # analytic value is a small difference of large sums and the fp32 oracle's own error is 1e-2 there - named, 8x instead of 4x
+        lim = 8 if k.endswith(".conv.bias") else 4
+        if e_hip > max(lim * e_ref, 2e-4):
             bad.append((k, e_hip, e_ref))
-    assert len(bad) <= len(ratios) // 100 and all(e <= max(8 * r, 2e-4) for _, e, r in bad), bad[:10]
-    assert sorted(ratios)[len(ratios) // 2] <= 2.0, sorted(ratios)[len(ratios) // 2]
+    assert not bad, bad[:10]                                   # per tensor: <= 4 x the fp32 oracle's own error (floor 2e-4)
+    assert sorted(ratios)[len(ratios) // 2] <= 1.5, sorted(ratios)[len(ratios) // 2]
     for k, b in model.named_buffers():                # running statistics after one training step, bracketed the same way
         if k.endswith("num_batches_tracked"):
             assert int(b) == int(b64[k]), k
@@ -554,6 +558,32 @@ def test_compact_skip_branch_equals_materialised(D):
         if diff > 4 * own + 1e-6:
             bad.append((k, diff, own))
     assert not bad, bad[:10]
+
+
+def test_grouped_encoders_equal_per_modality_encoders():
+    """MMVit4.grouped_encoders: the three modality encoders as one stacked pass (one grouped launch per twin layer, Z = 3) against one
+    Encoder.forward per modality on three streams.  Same kernels on the same tiles: the prediction, the loss and the BatchNorm running
+    statistics are bit-identical; the data gradients are the same launches too, so parameter gradients can only differ by the row-split
+    order of the weight-gradient reductions (a few ulp, no network amplification)."""
+    import ops
+    case = dict(B=3, D=3, H=64, W=64, mode="train_nodrop", conv_gain=1.0, wseed=13)
+    res = []
+    for grouped in (True, False):
+        model, _ = build_hip(case)
+        model.grouped_encoders = grouped
+        x, mask = helpers.make_inputs(case["B"], case["D"], case["H"], case["W"])
+        pred = model(x.to(DEV))
+        loss = ops.bce_with_logits_mean(pred, mask.to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((pred.detach(), loss.item(), {k: p.grad for k, p in model.named_parameters() if p.grad is not None},
+                    {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}))
+    (p1, l1, g1, b1), (p2, l2, g2, b2) = res
+    assert torch.equal(p1, p2) and l1 == l2
+    assert all(torch.equal(b1[k], b2[k]) for k in b1)
+    assert g1.keys() == g2.keys() and len(g1) == 1122
+    worst = max(((g1[k] - g2[k]).norm() / g2[k].norm().clamp_min(1e-30)).item() for k in g1)
+    assert worst < 1e-5, worst
 
 
 def test_determinism():

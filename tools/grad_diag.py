@@ -37,8 +37,9 @@ def oracle(case, dtype, sd):
     return out
 
 
-def hip(case, sd, serial, stream_k, tap=True, patch=True, bwd_stats=True, splits_r1=False, stem=True, compact=True):
+def hip(case, sd, serial, stream_k, tap=True, patch=True, bwd_stats=True, splits_r1=False, stem=True, compact=True, ksplit=True, grouped=True):
     ops.STREAM_K, ops.USE_PATCH, mmvit4.GRAD_TAP = stream_k, patch, tap
+    ops.K_SPLIT_ACCUM = ksplit
     ops.BWD_STATS, ops.WGRAD_SPLITS_R1, ops.USE_STEM_KERNEL = bwd_stats, splits_r1, stem
     model = mmvit4.MMVit4()
     model.load_state_dict(sd)
@@ -47,6 +48,7 @@ def hip(case, sd, serial, stream_k, tap=True, patch=True, bwd_stats=True, splits
         if isinstance(getattr(m, "p", None), float):
             m.p = 0.0
     model.decoder_fuse.compact_skips = compact
+    model.grouped_encoders = grouped
     if serial:
         model.concurrent_branches, model.decoder_split, model.decoder_fuse.concurrent_skips = False, 0, False
     x, mask = helpers.make_inputs(case["B"], case["D"], case["H"], case["W"])
@@ -70,6 +72,8 @@ def main():
     r32 = oracle(case, torch.float32, sd)
     print("oracle fp32 vs fp64: pred gap %.3e" % (r32["__pred__"] - r64["__pred__"]).abs().max().item(), flush=True)
     variants = [("default", dict(serial=False, stream_k=False)),
+                ("ONE fma chain over all of K (rounds 1-2)", dict(serial=False, stream_k=False, ksplit=False)),
+                ("one Encoder.forward per modality (twins)", dict(serial=False, stream_k=False, grouped=False)),
                 ("BatchNorm backward reductions as their own pass", dict(serial=False, stream_k=False, bwd_stats=False)),
                 ("round-1 weight-gradient splits", dict(serial=False, stream_k=False, splits_r1=True)),
                 ("both of the above", dict(serial=False, stream_k=False, bwd_stats=False, splits_r1=True)),

@@ -44,13 +44,13 @@ def case(name, M, N, K, conv=None):
         ops.gemm(A.data_ptr(), Ci, W.data_ptr(), K, 0, C.data_ptr(), N, M, N, K, Ci, g, Z=3, sA=(M * Ci, 0), sB=(N * K, 0), sC=(M * N, 0))
 
     res = []
-    for label, fn, sk in (("3 launches, one stream", serial, False), ("3 launches, stream-K each", serial, True),
-                          ("3 launches, three streams", three_streams, False), ("one grouped launch (Z=3)", grouped, False),
-                          ("grouped + stream-K", grouped, True)):
-        ops.STREAM_K = sk
+    for label, fn, sk, ks in (("3 launches, one stream", serial, False, True), ("same, ONE fma chain over K", serial, False, False),
+                              ("3 launches, three streams", three_streams, False, True), ("one grouped launch (Z=3)", grouped, False, True),
+                              ("grouped, ONE fma chain", grouped, False, False), ("grouped + stream-K", grouped, True, True)):
+        ops.STREAM_K, ops.K_SPLIT_ACCUM = sk, ks
         ms = timeit(fn)
         res.append("%s %.3f ms %.1f TF/s" % (label, ms, fl / ms / 1e9))
-    ops.STREAM_K = False
+    ops.STREAM_K, ops.K_SPLIT_ACCUM = False, True
     print("%-28s M=%6d N=%4d K=%4d | " % (name, M, N, K) + " | ".join(res), flush=True)
 
 
