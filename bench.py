@@ -227,6 +227,13 @@ class HbmTimer:
         return out
 
 
+def helpers_free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -299,6 +306,11 @@ def main():
             dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
+        if os.environ.get("CORRIF_FORCE_COLLECTIVE") == "1":      # rehearsal: the N > 1 gradient path (bucket gather + RCCL all-reduce) with one rank
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(helpers_free_port()))
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     dev = torch.device("cuda", local if world > 1 else 0)
 
     import mmvit4
@@ -343,7 +355,7 @@ def main():
         model.decoder_fuse.concurrent_skips = False
         model.decoder_split = 0
     broadcast_module_state(model)
-    reducer = GradAllReducer(model)
+    reducer = GradAllReducer(model, force_collective=os.environ.get("CORRIF_FORCE_COLLECTIVE") == "1")
     B = args.batch
     xg, maskg = helpers.make_inputs(B, args.bands, args.size, args.size, seed=1234 + rank)   # rank r's own shard
     x, mask = xg.to(dev), maskg.to(dev)
@@ -421,7 +433,8 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "mmvit4 CorrIFNet fwd+loss+bwd, %d bands/modality, %dx%d, batch %d per GPU, train mode %s"
                                       % (args.bands, args.size, args.size, B, label),
-                          "global_batch": world * B, "parallelism": "dp%d" % world, "loss": float(loss.item()),
+                          "global_batch": world * B, "parallelism": "dp%d" % world + (" (one rank, collectives forced)" if reducer.force else ""),
+                          "loss": float(loss.item()),
                           "peak_mem_GB": round(peak_mem / 1e9, 2),
                           "encoder_schedule": "grouped (one launch per twin layer of the three modality encoders)"
                                               if model.encoders_grouped_for(x) else "per modality on three streams"}}
@@ -485,7 +498,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -433,30 +433,60 @@ __device__ __forceinline__ void axis_range(const Axis& a, int i, int& lo, int& h
     if (lo < 0) lo = 0;
     if (hi > a.out - 1) hi = a.out - 1;
 }
+// the outputs that read input index i along one axis and their weights, scanned ONCE per axis (up to NT of them: 2-5 for the x2
+// up-samplings, 1-2 for the down-samplings to 8^3); returns the count, or -1 when there are more than NT (generic fall-back below)
+template <int NT>
+__device__ __forceinline__ int axis_tap_list(const Axis& a, int i, int (&idx)[NT], float (&wt)[NT]) {
+    int lo, hi, n = 0;
+    axis_range(a, i, lo, hi);
+    for (int o = lo; o <= hi; ++o) {
+        const float w = axis_weight(a, o, i);
+        if (w == 0.f) continue;
+        if (n == NT) return -1;
+        idx[n] = o;
+        wt[n] = w;
+        ++n;
+    }
+    return n;
+}
 __global__ void trilinear_bwd_kernel(const float* __restrict__ dy, int64_t lddy, float* __restrict__ dx, int64_t lddx, int B, int C4,
                                      Axis ad, Axis ah, Axis aw, Dec5 q) {
+    constexpr int NT = 6;
     int64_t total = (int64_t)B * ad.in * ah.in * aw.in * C4;
     GRID_STRIDE(i, total) {
         int c, wi, hi_, di, bi;
         dec5((uint32_t)i, q, bi, di, hi_, wi, c);
         const int64_t b = bi;
-        int dlo, dhi, hlo, hhi, wlo, whi;
-        axis_range(ad, di, dlo, dhi);
-        axis_range(ah, hi_, hlo, hhi);
-        axis_range(aw, wi, wlo, whi);
         f32x4 acc = {0, 0, 0, 0};
         const float* gb = dy + b * ad.out * ah.out * aw.out * lddy + c * 4;
-        for (int dd = dlo; dd <= dhi; ++dd) {
-            float wd = axis_weight(ad, dd, di);
-            if (wd == 0.f) continue;
-            for (int ho = hlo; ho <= hhi; ++ho) {
-                float wh = axis_weight(ah, ho, hi_);
-                if (wh == 0.f) continue;
-                for (int wo = wlo; wo <= whi; ++wo) {
-                    float ww = axis_weight(aw, wo, wi);
-                    if (ww == 0.f) continue;
-                    f32x4 g = *reinterpret_cast<const f32x4*>(gb + ((int64_t)(dd * ah.out + ho) * aw.out + wo) * lddy);
-                    acc += (wd * wh * ww) * g;
+        int id[NT], ih[NT], iw[NT];
+        float fd[NT], fh[NT], fw[NT];
+        const int nd = axis_tap_list<NT>(ad, di, id, fd), nh = axis_tap_list<NT>(ah, hi_, ih, fh), nw = axis_tap_list<NT>(aw, wi, iw, fw);
+        if (nd >= 0 && nh >= 0 && nw >= 0) {
+            // same summation order as the generic loop (ascending output index per axis, weight product (wd * wh) * ww): bit-identical
+            for (int a = 0; a < nd; ++a)
+                for (int e = 0; e < nh; ++e) {
+                    const float wdh = fd[a] * fh[e];
+                    const float* row = gb + (int64_t)(id[a] * ah.out + ih[e]) * aw.out * lddy;
+                    for (int f = 0; f < nw; ++f) acc += (wdh * fw[f]) * *reinterpret_cast<const f32x4*>(row + (int64_t)iw[f] * lddy);
+                }
+        } else {
+            int dlo, dhi, hlo, hhi, wlo, whi;
+            axis_range(ad, di, dlo, dhi);
+            axis_range(ah, hi_, hlo, hhi);
+            axis_range(aw, wi, wlo, whi);
+            for (int dd = dlo; dd <= dhi; ++dd) {
+                float wd = axis_weight(ad, dd, di);
+                if (wd == 0.f) continue;
+                for (int ho = hlo; ho <= hhi; ++ho) {
+                    float wh = axis_weight(ah, ho, hi_);
+                    if (wh == 0.f) continue;
+                    for (int wo = wlo; wo <= whi; ++wo) {
+                        float ww = axis_weight(aw, wo, wi);
+                        if (ww == 0.f) continue;
+                        f32x4 g = *reinterpret_cast<const f32x4*>(gb + ((int64_t)(dd * ah.out + ho) * aw.out + wo) * lddy);
+                        acc += (wd * wh * ww) * g;
+                    }
                 }
             }
         }

@@ -578,13 +578,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         part[((int64_t)blockIdx.x * C + c) * 2 + 1] = b;
     }
 }
-__global__ void layernorm_bwd_final_kernel(const double* __restrict__ part, int nblk, int C, float* dgamma, float* dbeta) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per channel: the lanes stride over the per-block partials, fixed-order butterfly in double (the serial loop of round 1-2,
+// one thread per channel over up to 1024 partials, took 157 us per call - launch-latency class work that sat exposed 8x per step)
+__global__ __launch_bounds__(256) void layernorm_bwd_final_kernel(const double* __restrict__ part, int nblk, int C, float* dgamma, float* dbeta) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     double a = 0, b = 0;
-    for (int k = 0; k < nblk; ++k) { a += part[((int64_t)k * C + c) * 2]; b += part[((int64_t)k * C + c) * 2 + 1]; }
-    dgamma[c] = (float)a;
-    dbeta[c] = (float)b;
+    for (int k = lane; k < nblk; k += 64) { a += part[((int64_t)k * C + c) * 2]; b += part[((int64_t)k * C + c) * 2 + 1]; }
+    wave_sum2(a, b);
+    if (lane == 0) {
+        dgamma[c] = (float)a;
+        dbeta[c] = (float)b;
+    }
 }
 static int ln_blocks(int64_t rows, int& rpb) {
     int64_t nb = (rows + 31) / 32;
@@ -620,7 +626,7 @@ extern "C" int corrif_layernorm_bwd(const float* dy, const float* x, const float
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL((layernorm_bwd_kernel<2>), dim3(nb), dim3(256), 0, s, dy, x, mean, rstd, gamma, dx, ws, rows, rpb);
     CORRIF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)ws, nb, (int)C, dgamma, dbeta);
+    hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, s, (const double*)ws, nb, (int)C, dgamma, dbeta);
     CORRIF_CHECK_LAUNCH();
     return CORRIF_OK;
 }

@@ -63,9 +63,11 @@ STREAM_K = False
 # STREAM_K_LONG restricts it to where it helps a launch in isolation: long K loops on a small tile grid (e4 / e5's 3x3 convolutions and
 # their data gradients: 392 / 196 tiles of 128 x 128 on 512 slots, 72 / 144 K tiles; 84 -> 98 TFLOP/s alone, tools/gemm_lab.hip).
 STREAM_K_LONG = False     # measured (round 2): wall-neutral on the B=32 step (248.4 vs 248.0 ms), the branch streams already fill those tails
-# Grouped launches (Z = 3 twin layers of the modality encoders) with a long K loop: the split pays (tools/group_microbench.py, round 3: e4 conv2
-# 99 -> 106 TFLOP/s, e5 conv2 85 -> 108, e5 conv1 92 -> 102) while short-K shapes lose 8-9 % to the slab round trip (K <= 1024).
-STREAM_K_GROUPED = True
+# Grouped launches (Z = 3 twin layers of the modality encoders) with a long K loop: the split pays in isolation (tools/group_microbench.py,
+# round 3: e4 conv2 99 -> 106 TFLOP/s, e5 conv2 85 -> 108, e5 conv1 92 -> 102) while short-K shapes lose 8-9 % to the slab round trip
+# (K <= 1024); on the B=32 step it is worth 0.8 ms of 254 (A/B, one box) - and it re-associates the K sum, so the grouped schedule would
+# no longer be bit-identical to the per-modality one.  Off: the two encoder schedules produce the same bits (tests/test_model_gpu.py).
+STREAM_K_GROUPED = False
 # Two-level K accumulation of the forward / data-gradient GEMMs (CorrifGemm.no_ksplit = 0): a fresh fma chain every 512 products.  One
 # chain over all of K has 1.9x (K = 1024) ... 4.5x (K = 4608-8640) ATen's local error against fp64 (tools/local_error.py; oneDNN
 # accumulates in blocks), with it the kernels sit at ATen's level - at 7-9 % of the long-K launches' time (the second accumulator set
@@ -788,7 +790,7 @@ class GroupedConvFn(Function):
             if has_bias and ctx.needs_input_grad[2]:
                 gb = torch.empty((G, Co), dtype=torch.float32, device=dev)
                 if zout == "stack":
-                    ws = _ws(lib().corrif_norm_workspace(M, G, Co), dev)
+                    ws = _ws(lib().corrif_norm_workspace_g(M, G, Co), dev)
                     check(lib().corrif_col_sum_g(P(gy), ldg, M, G, Co, P(gb), P(ws), stream()), "corrif_col_sum_g")
                 else:                                     # concat layout: the column sums of the [M][G*Co] gradient ARE [G][Co]
                     ws = _ws(lib().corrif_col_sum_workspace(M, G * Co), dev)

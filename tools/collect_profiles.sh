@@ -9,7 +9,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/concurrent -o c --output-format csv -- python $R/bench.py $ARGS > $O/concurrent.log 2>&1 || echo "concurrent failed"
-python $R/tools/timeline.py $O/concurrent/c_kernel_trace.csv 250 > $O/timeline.txt 2>&1
+python $R/tools/timeline.py $O/concurrent/c_kernel_trace.csv 244 > $O/timeline.txt 2>&1
 export CORRIF_SERIAL=1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/serial -o s --output-format csv -- python $R/bench.py $ARGS > $O/serial.log 2>&1 || echo "serial failed"
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/fetch.log 2>&1 || echo "fetch failed"

@@ -9,7 +9,7 @@ t_end = max(e[1] for e in ev)
 span = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else 345e6
 t0 = t_end - span
 ev = [e for e in ev if e[1] > t0]
-def is_mfma(n): return any(k in n for k in ("gemm_fwd_kernel", "wgrad_kernel", "conv3_patch", "smalln_fwd", "smallm_wgrad", "conv1x1_small", "flash_fwd", "flash_bwd", "stem_fwd", "stem_wgrad"))
+def is_mfma(n): return any(k in n for k in ("gemm_fwd_kernel", "gemm_sk_kernel", "gemm_sk_fixup", "wgrad_kernel", "conv3_patch", "smalln_fwd", "smallm_wgrad", "conv1x1_small", "flash_fwd", "flash_bwd", "stem_fwd", "stem_wgrad"))
 pts = []
 for s, e, n, q in ev:
     s = max(s, t0)
