@@ -6,6 +6,7 @@ sample-group lane's gradient into the decoder / multimodal-transformer parameter
 possibly as a channel-slice view of a wider concat buffer (row pitch `ld` > C).
 """
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -15,6 +16,36 @@ from corrif_hip import P, check, lib, stream
 
 NORM_RELU_IN, NORM_RELU_OUT = 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+# ---- TORCH_LIBRARY binding of the same C-ABI (csrc_torch/corrif_torch.cpp -> libcorrif_torch.so): torch.ops.corrif.* for the NO-GRAD
+# forward of the convolution / BatchNorm / InstanceNorm / Linear families - the op validates, allocates and fills the C-ABI descriptor
+# in C++, so an eval forward (F4_TRAIN.py:181-208, allJaccardResults_irem_f1_jcrd.py:201-222: launch-bound at batch 1) spends no Python
+# per launch on these ~430 of its ~700 launches.  The training path (autograd.Function objects below) uses the ctypes binding.
+# CORRIF_TORCH_LIBRARY=0 (or ops.USE_TORCH_LIBRARY = False) routes everything through ctypes (A/B, diagnostics).
+USE_TORCH_LIBRARY = os.environ.get("CORRIF_TORCH_LIBRARY", "1") != "0"
+_tl = None
+
+
+def tl():
+    """torch.ops.corrif, loading libcorrif_torch.so on first use; None when the binding is switched off"""
+    global _tl
+    if not USE_TORCH_LIBRARY:
+        return None
+    if _tl is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcorrif_torch.so")
+        if not os.path.exists(path):
+            raise RuntimeError("corrif: %s not found - build it with `python __graft_entry__.py` (or set CORRIF_TORCH_LIBRARY=0 to use the "
+                               "ctypes binding of the same kernels only)" % path)
+        lib()                                   # libcorrif_gfx950.so first: the shim links against it
+        torch.ops.load_library(path)
+        _tl = torch.ops.corrif
+    return _tl
+
+
+def _fast():
+    """the TORCH_LIBRARY ops serve this call: no autograd graph is being recorded and the kernel-variant switches are at their defaults"""
+    return USE_TORCH_LIBRARY and not torch.is_grad_enabled() and not (STREAM_K or STREAM_K_LONG or K_SPLIT_ACCUM) and USE_PATCH and \
+        USE_STEM_KERNEL and PATCH_STATS
 
 
 # --------------------------------------------------------------------------------------- helpers
@@ -576,6 +607,12 @@ def conv3d(x, weight, bias=None, stride=(1, 1, 1), pad=(0, 0, 0), replicate=Fals
         bcast = None              # only the patch kernel's epilogue can absorb the depth-class add (bcast["done"] stays False: the caller adds)
     if bcast is None and stats is not None and stats.get("after_bcast"):
         stats = None              # the statistics must see the sum: without the fused add they are taken by the norm's own pass
+    if bcast is None and act == ACT_NONE and grad_link is None and _fast():
+        y, part, chunks, rpg = tl().conv3d_fwd(x, weight, bias, list(stride), list(pad), bool(replicate), out,
+                                                stats["G"] if stats is not None else 0, bool(stats["relu"]) if stats is not None else False)
+        if stats is not None and part.numel():
+            stats["part"], stats["chunks"], stats["rpg"] = part, chunks, rpg
+        return y
     return ConvFn.apply(x, weight, bias, tuple(stride), tuple(pad), bool(replicate), out, act, stats, grad_link, bool(side_wgrad), bwd_stats, bcast)
 
 
@@ -815,6 +852,9 @@ def _bwd_stats_request_g(bl, grad_link, rows, C, G, dev, xin, ldin):
 def conv3d_grouped(x, weights, biases, stride, pad, zin="stack", zout="stack", out=None, stats=None, grad_link=None, bwd_stats=None):
     """weights / biases: the G twin modules' parameters (lists); see GroupedConvFn"""
     G = len(weights)
+    if stats is None and grad_link is None and _fast():
+        return tl().conv3d_grouped_fwd(x, list(weights), [] if biases[0] is None else list(biases), list(stride), list(pad),
+                                       0 if zin == "stack" else 1, 0 if zout == "stack" else 1, out)
     w = stack_params(weights)
     b = stack_params(biases) if biases[0] is not None else None
     # the side-stream weight gradient is only safe when autograd will ADOPT the produced gradients (no accumulation kernel on another stream)
@@ -898,6 +938,8 @@ class GroupedBatchNormFn(Function):
 def batch_norm_grouped(x, gammas, betas, running_means, running_vars, residual=None, relu_in=False, relu_out=False, training=True,
                        momentum=0.1, eps=1e-5, out=None, pre=None, bwd_link=None):
     flags = (NORM_RELU_IN if relu_in else 0) | (NORM_RELU_OUT if relu_out else 0)
+    if not training and out is None and _fast():
+        return tl().batch_norm_grouped_eval(x, list(gammas), list(betas), list(running_means), list(running_vars), residual, flags, eps)
     return GroupedBatchNormFn.apply(x, stack_params(gammas), stack_params(betas), list(running_means), list(running_vars), residual, flags,
                                     training, momentum, eps, out, pre, bwd_link, len(gammas))
 
@@ -988,7 +1030,10 @@ class LinearFn(Function):
         return gx, gw, gb
 
 
-linear = LinearFn.apply
+def linear(x, weight, bias):
+    if _fast():
+        return tl().linear_fwd(x, weight, bias)
+    return LinearFn.apply(x, weight, bias)
 
 
 # --------------------------------------------------------------------------------------- BatchNorm / InstanceNorm
@@ -1072,6 +1117,8 @@ class BatchNormFn(Function):
 def batch_norm(x, gamma, beta, running_mean, running_var, residual=None, relu_in=False, relu_out=False, training=True,
                momentum=0.1, eps=1e-5, out=None, pre=None, bwd_link=None):
     flags = (NORM_RELU_IN if relu_in else 0) | (NORM_RELU_OUT if relu_out else 0)
+    if not training and _fast():
+        return tl().batch_norm_eval(x, gamma, beta, running_mean, running_var, residual, flags, eps, out)
     return BatchNormFn.apply(x, gamma, beta, running_mean, running_var, residual, flags, training, momentum, eps, out, pre, bwd_link)
 
 
@@ -1117,7 +1164,17 @@ class ReluInstNormFn(Function):
         return gx, None, None, None
 
 
+_NO_PART = {}
+
+
 def relu_instnorm(x, eps=1e-5, out=None, pre=None):
+    if _fast():
+        if pre is not None and "part" in pre and pre["G"] == x.shape[0] and pre["relu"]:
+            return tl().relu_instnorm_fwd(x, eps, out, pre["part"], pre["chunks"], pre["rpg"])
+        key = x.device
+        if key not in _NO_PART:
+            _NO_PART[key] = torch.empty(0, dtype=torch.float64, device=x.device)
+        return tl().relu_instnorm_fwd(x, eps, out, _NO_PART[key], 0, 0)
     return ReluInstNormFn.apply(x, eps, out, pre)
 
 

@@ -41,6 +41,17 @@ def test_library_exports_every_declared_symbol(built):
     assert lib.corrif_wgrad_plan(6272, 512, 4608, 1) >= 1
 
 
+def test_torch_library_binding_loads_and_registers_its_ops(built):
+    """libcorrif_torch.so (TORCH_LIBRARY shim over the same C-ABI, csrc_torch/corrif_torch.cpp) loads next to the kernel library and
+    registers the ops the no-grad forward path dispatches to (no compute calls without a GPU)."""
+    import ops
+    t = ops.tl()
+    for name in ("conv3d_fwd", "conv3d_grouped_fwd", "batch_norm_eval", "batch_norm_grouped_eval", "relu_instnorm_fwd", "linear_fwd"):
+        assert hasattr(t, name), name
+    schema = str(torch.ops.corrif.conv3d_fwd.default._schema)
+    assert "Tensor x" in schema and "int[] stride" in schema and "Tensor? out" in schema
+
+
 def test_ctypes_struct_layout_matches_header(built):
     """sizeof/offsetof agreement between the ctypes mirrors and the C structs (compiled with the host compiler)."""
     import corrif_hip as H

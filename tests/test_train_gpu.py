@@ -215,6 +215,27 @@ def test_reducer_rccl_path_single_rank():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("B", [1, 8])
+def test_torch_library_binding_equals_ctypes_binding(B):
+    """The eval forward (F4_TRAIN.py:181-208) through torch.ops.corrif.* (descriptors filled in C++, csrc_torch/corrif_torch.cpp) against
+    the same forward through the ctypes binding: the same kernels with the same arguments, bit-identical.  B = 1 runs the grouped
+    encoder ops (conv3d_grouped_fwd / batch_norm_grouped_eval), B = 8 the per-modality ones."""
+    import ops
+    _, hip = _models(seed=29, train=False)
+    x, _ = helpers.make_inputs(B, 3, 96, 96, seed=5)
+    x = x.to(DEV)
+    assert ops.USE_TORCH_LIBRARY and ops.tl() is not None
+    with torch.no_grad():
+        y1 = hip(x).clone()
+        was, ops.USE_TORCH_LIBRARY = ops.USE_TORCH_LIBRARY, False
+        try:
+            y2 = hip(x).clone()
+        finally:
+            ops.USE_TORCH_LIBRARY = was
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+
+
 def test_hip_graph_eval_forward_is_bit_identical_to_eager():
     """train.GraphedForward: the eval forward captured in a HIP graph WITH the module's multi-stream schedule (branch streams,
     sample-group lanes, decoder skip stream) replays to the eager result, also for a second input written into the static buffer;

@@ -4,10 +4,18 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["Queue_Id"])) for r in rows]
 ev.sort()
-# find the last step: bce kernel marks the fwd/bwd boundary; take from the previous step's end.  Simpler: last `span` ms
-t_end = max(e[1] for e in ev)
-span = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else 345e6
-t0 = t_end - span
+# one whole step = the interval between the last two loss kernels (backward of step k + forward of step k+1); the optional second
+# argument (ms, counted back from the end of the trace) is the fall-back when the trace holds fewer than two of them
+marks = sorted(e[0] for e in ev if "bce_kernel" in e[2])
+if len(marks) >= 2:
+    t0, t_end = marks[-2], marks[-1]
+    span = float(t_end - t0)
+else:
+    t_end = max(e[1] for e in ev)
+    span = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else 345e6
+    t0 = t_end - span
+ev = [e for e in ev if e[0] < t_end]
+print("window: %.1f ms" % (span / 1e6))
 ev = [e for e in ev if e[1] > t0]
 def is_mfma(n): return any(k in n for k in ("gemm_fwd_kernel", "gemm_sk_kernel", "gemm_sk_fixup", "wgrad_kernel", "conv3_patch", "smalln_fwd", "smallm_wgrad", "conv1x1_small", "flash_fwd", "flash_bwd", "stem_fwd", "stem_wgrad"))
 pts = []
