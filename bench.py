@@ -367,11 +367,13 @@ def main():
         loss = ops.bce_with_logits_mean(pred, mask)     # F4_TRAIN.py:58-60
         loss.backward()
         reducer.finish()
-        return loss
+        return loss.detach()
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    warm_peak = torch.cuda.max_memory_allocated()
+    torch.cuda.reset_peak_memory_stats()             # peak_mem_GB below = the timed steps' own peak (the bench's statistic, not the model's)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -383,7 +385,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    peak_mem = torch.cuda.max_memory_allocated()     # since the model's last memory-plan measurement (its first steps reset the peak statistics)
+    peak_mem = torch.cuda.max_memory_allocated()     # of the timed steps
     kt_steps = 0
     if timer:
         # EVERY rank runs this pass (its steps contain the gradient all-reduces: a rank-0-only pass would leave the collectives
@@ -435,7 +437,7 @@ def main():
                                       % (args.bands, args.size, args.size, B, label),
                           "global_batch": world * B, "parallelism": "dp%d" % world + (" (one rank, collectives forced)" if reducer.force else ""),
                           "loss": float(loss.item()),
-                          "peak_mem_GB": round(peak_mem / 1e9, 2),
+                          "peak_mem_GB": round(peak_mem / 1e9, 2), "peak_mem_warmup_GB": round(warm_peak / 1e9, 2),
                           "encoder_schedule": "grouped (one launch per twin layer of the three modality encoders)"
                                               if model.encoders_grouped_for(x) else "per modality on three streams"}}
         # HBM bytes of the MFMA kernel family for ONE step of this workload, from the newest committed rocprofv3 PMC passes

@@ -20,9 +20,28 @@ import ops
 
 # The decoder / multimodal-transformer parameters are used by two sample-group lanes on two streams (MMVit4.decoder_split), so the second
 # lane's gradient reaches an AccumulateGrad node that lives on the first lane's stream: autograd inserts the stream wait the accumulation
-# needs and warns that the streams differ.  The mismatch is intentional here.
-if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
-    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+# needs and warns that the streams differ.  The mismatch is intentional here, and the warning is switched off for the duration of THIS
+# model's backward pass only (`_QuietBackwardFn` on the prediction: its backward is the first node of the pass and an engine callback
+# restores the switch at the end), not for the process (round 2 flipped it at import time).
+_WARN_SWITCH = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+
+
+def _restore_warning():
+    if _WARN_SWITCH is not None:
+        _WARN_SWITCH(True)
+
+
+class _QuietBackwardFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred):
+        return pred.view_as(pred)
+
+    @staticmethod
+    def backward(ctx, g):
+        if _WARN_SWITCH is not None:
+            _WARN_SWITCH(False)
+            torch.autograd.Variable._execution_engine.queue_callback(_restore_warning)
+        return g
 
 basic_dims = 8
 transformer_basic_dims = 512
@@ -660,8 +679,10 @@ class MMVit4(nn.Module):
         # more evenly than three small ones (encoder GEMMs +10-25 % in isolation).  The price is the overlap of one branch's HBM-bound
         # BatchNorm passes with another branch's matrix work, which only the three-stream schedule has.  Measured (round 3, fwd+bwd,
         # 4 bands 224^2, ms per step grouped / per modality): B=32 259 / 247, B=16 135 / 129, B=8 75.0 / 73.4, B=4 45.7 / 62.2,
-        # B=2 44.0 / 58.5.  None = choose per call (encoders_grouped_for): grouped when the step is launch-bound (small batches) or the
-        # schedule is single-stream anyway (near the HBM capacity, CORRIF_SERIAL), per modality otherwise; True / False force one.
+        # B=2 44.0 / 58.5.  None = choose per call (encoders_grouped_for): grouped when the step is launch-bound (small batches), per
+        # modality otherwise; True / False force one.  NOT grouped near the HBM capacity even though that schedule is single-stream anyway:
+        # the stacked activations are 3x larger allocations and the caching allocator then fragments (B = 64, 8 bands, 256^2: 3.5 s per
+        # step grouped vs 1.0 s per modality at the same 230 GB peak; 12 bands 512^2 at B = 16: 4.5 s vs 1.17 s).
         self.grouped_encoders = None
         self._gcache = None
         self.interleave_branches = True      # enqueue the three branches layer by layer in turn (diagnostics / A-B: False = branch after branch)
@@ -722,32 +743,37 @@ class MMVit4(nn.Module):
 
     def _wants_single_stream(self, x):
         """Memory plan per input shape.  The first training step at a shape is scheduled from an a-priori estimate of its autograd state
-        (`_memory_limited`); the next three steps from the MEASURED peak of the step before (torch.cuda.max_memory_allocated, reset at
-        those forwards): multi-stream while the peak stays under 55 % of the device memory, single-stream above 75 %, no change in
-        between (the multi-stream schedule itself needs more than the single-stream one: per-stream pools).  After that the plan of the
-        shape is final and the process-wide peak statistics are not touched any more."""
+        (`_memory_limited`); the following steps from what the steps before it NEEDED, read off the process-wide high-water mark
+        `torch.cuda.max_memory_allocated` - which is only read, never reset (round 2 reset it around its measurements and so clobbered
+        the caller's statistics): when the mark rose during this shape's steps it IS their peak, otherwise it is an upper bound of it.
+        Multi-stream while that stays under 55 % of the device memory, single-stream above 75 %, no change in between (the multi-stream
+        schedule needs more than the single-stream one: per-stream pools).  A change of schedule restarts the three-step window, so a
+        flip to multi-stream that then exceeds 75 % is taken back; after three steps without a change the plan of the shape is final."""
         key, dev = tuple(x.shape), x.device
         total = torch.cuda.get_device_properties(dev).total_memory
+        peak = torch.cuda.max_memory_allocated(dev)
         plan = self._mem_plan.get(key)
         if plan is None:
-            plan = self._mem_plan[key] = [_memory_limited(x), 0]         # [single-stream?, measured steps]
-        elif plan[1] < 3:
-            peak = torch.cuda.max_memory_allocated(dev)
-            if peak > 0.75 * total:
-                plan[0] = True
-            elif peak < 0.55 * total:
-                plan[0] = False
-            plan[1] += 1
-        if plan[1] < 3:                       # measuring: afterwards the decision is final and the caller's peak statistics are left alone
-            torch.cuda.reset_peak_memory_stats(dev)
-        return plan[0]
+            self._mem_plan[key] = plan = {"single": _memory_limited(x), "steps": 0, "mark": peak}
+            return plan["single"]
+        if plan["steps"] < 3:
+            if peak < plan["mark"]:               # the caller reset the statistics in between: this sample says nothing about the step
+                plan["mark"] = peak
+                return plan["single"]
+            rose = peak > plan["mark"]
+            if rose and peak > 0.75 * total and not plan["single"]:
+                plan["single"], plan["steps"] = True, 0
+            elif peak < 0.55 * total and plan["single"]:
+                plan["single"], plan["steps"] = False, 0
+            else:
+                plan["steps"] += 1
+            plan["mark"] = peak
+        return plan["single"]
 
     def encoders_grouped_for(self, x):
         """the encoder schedule `forward` uses for input x under the current switches (see __init__)"""
         if self.grouped_encoders is not None:
             return bool(self.grouped_encoders)
-        if not self.concurrent_branches:
-            return True                        # one stream: nothing to overlap, the larger launches are a pure gain
         B, _, D, Hh, W = x.shape
         rows_e4 = B * D * ((Hh + 15) // 16) * ((W + 15) // 16)          # GEMM rows of one modality at the e4 level
         return rows_e4 < 5000                  # B <= 6 at 4 bands 224^2: one modality's launches leave most of the 256 CUs idle
@@ -887,7 +913,10 @@ class MMVit4(nn.Module):
             x6 = self.multimodal_decode_conv(y.view(nb, P3, P3, P3, 4 * T))                # 4 tokens -> one voxel (mmvit4.py:526)
             return self.decoder_fuse(f1, f2, f3, f4, x6, lane=lane)
 
-        return _run_lanes(self, tail, pos, tokens, fused[0], fused[1], fused[2], fused[3])
+        pred = _run_lanes(self, tail, pos, tokens, fused[0], fused[1], fused[2], fused[3])
+        if pred.requires_grad and int(self.decoder_split or 0) >= 2:
+            pred = _QuietBackwardFn.apply(pred)
+        return pred
 
 
 def _memory_limited(x, frac=0.6):

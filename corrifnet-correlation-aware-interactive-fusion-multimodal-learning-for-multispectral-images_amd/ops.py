@@ -932,6 +932,7 @@ class GroupedBatchNormFn(Function):
             check(lib().corrif_norm_bwd_g(P(gy), ldg, P(y), ldy, P(x), ldx, P(mean), P(rstd), P(gamma), P(gx), C, P(gres), C, P(ggamma),
                                           P(gbeta), rpg, G, C, flags, 1 if frozen else 0, C, P(ws), stream()), "corrif_norm_bwd_g")
             NORM_BWD_STATS["pass"] += G
+        _drop_link(bl)
         return gx, ggamma, gbeta, None, None, gres, None, None, None, None, None, None, None, None
 
 
@@ -1044,6 +1045,17 @@ def _norm_ws(rows_per_group, G, C, dev):
 NORM_BWD_STATS = {"epilogue": 0, "pass": 0}      # BatchNorm backwards whose reduction came from a GEMM epilogue / ran as its own pass (tests)
 
 
+def _drop_link(bl):
+    """The backward-statistics link of a BatchNorm (a plain dict reachable from the autograd nodes' ctx objects) holds the layer's input
+    activations.  Saved tensors are released by the backward pass, Python attributes of a ctx are not: a caller that keeps `loss` alive
+    into the next step (`loss = criterion(...)` ... `loss.item()` as F4_TRAIN.py:58-64 does) would keep every BatchNorm input of the
+    previous step alive with it (+35 GB at B = 32, 8 bands, 256^2).  Called at the end of the BatchNorm's backward, when nothing reads
+    the link any more."""
+    if bl is not None:
+        for k in ("x", "mean", "rstd", "part"):
+            bl.pop(k, None)
+
+
 class BatchNormFn(Function):
     """y = act_out(gamma * (x' - mean) * rstd + beta + residual), x' = relu(x) if relu_in.  Statistics over all rows."""
 
@@ -1111,6 +1123,7 @@ class BatchNormFn(Function):
             check(lib().corrif_norm_bwd(P(gy), ldg, P(y), ldy, P(x), ldx, P(mean), P(rstd), P(gamma), P(gx), C, P(gres), C,
                                         P(ggamma), P(gbeta), rows, 1, C, flags, 1 if frozen else 0, P(ws), stream()), "corrif_norm_bwd")
             NORM_BWD_STATS["pass"] += 1
+        _drop_link(bl)
         return gx, ggamma, gbeta, None, None, gres, None, None, None, None, None, None, None
 
 
