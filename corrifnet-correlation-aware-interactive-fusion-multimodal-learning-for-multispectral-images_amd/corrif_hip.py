@@ -109,6 +109,8 @@ _SIGS = {
     "corrif_maxpool133_bwd": (i32, [ptr, ptr, ptr, i32, i32, i32, i32, i32, ptr]),
     "corrif_trilinear_fwd": (i32, [ptr, i64, ptr, i64] + [i32] * 8 + [ptr]),
     "corrif_trilinear_bwd": (i32, [ptr, i64, ptr, i64] + [i32] * 8 + [ptr]),
+    "corrif_trilinear_bwd_sep_workspace": (i64, [i32] * 8),
+    "corrif_trilinear_bwd_sep": (i32, [ptr, ptr, ptr] + [i32] * 8 + [ptr]),
     "corrif_nearest_fwd": (i32, [ptr, i64, ptr, i64] + [i32] * 8 + [ptr]),
     "corrif_nearest_bwd": (i32, [ptr, i64, ptr, i64] + [i32] * 8 + [ptr]),
     "corrif_pad_fold": (i32, [ptr, ptr, i64, i32, i32, i32, i32, i32, ptr]),

@@ -244,6 +244,7 @@ def stem_wgrad(x, batch_pitch, gy, ldg, gwp, B, D, Hh, W):
 
 USE_PATCH = True      # diagnostics: False routes the narrow 3x3x3 layers through the implicit-GEMM kernels instead of the patch kernels
 PATCH_STATS = True    # diagnostics / A-B: False = the InstanceNorm after a patch-kernel convolution takes its statistics in its own pass
+TRILINEAR_SEPARABLE = True   # A-B: False = the adjoint of every trilinear up-sampling is the one-pass gather (rounds 1-2)
 
 
 def _patch_cc(k, stride, pad, Ci, Co):
@@ -1546,6 +1547,12 @@ class ResampleFn(Function):
         mode, (B, Di, Hi, Wi, C), (Do, Ho, Wo) = ctx.cfg
         g, _, ldg = rows_view(g)
         gx = torch.empty((B, Di, Hi, Wi, C), dtype=torch.float32, device=g.device)
+        if mode == "trilinear" and TRILINEAR_SEPARABLE and ldg == C and Do * Ho * Wo >= 4 * Di * Hi * Wi and g.numel() >= (1 << 20):
+            need = lib().corrif_trilinear_bwd_sep_workspace(B, C, Di, Hi, Wi, Do, Ho, Wo)
+            if need >= 0:         # the decoder's x2 up-samplings: one axis per pass, every incoming gradient read once
+                ws = torch.empty(need // 4, dtype=torch.float32, device=g.device)
+                check(lib().corrif_trilinear_bwd_sep(P(g), P(gx), P(ws), B, C, Di, Hi, Wi, Do, Ho, Wo, stream()), "corrif_trilinear_bwd_sep")
+                return gx, None, None, None
         fn = lib().corrif_trilinear_bwd if mode == "trilinear" else lib().corrif_nearest_bwd
         check(fn(P(g), ldg, P(gx), C, B, C, Di, Hi, Wi, Do, Ho, Wo, stream()), "corrif_%s_bwd" % mode)
         return gx, None, None, None

@@ -319,6 +319,13 @@ int corrif_trilinear_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, int
                          int32_t Di, int32_t Hi, int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, void* stream);
 int corrif_trilinear_bwd(const float* dy, int64_t lddy, float* dx, int64_t lddx, int32_t B, int32_t C,
                          int32_t Di, int32_t Hi, int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, void* stream);
+/* The same adjoint for a pure up-sampling (Do>=Di, Ho>=Hi, Wo>=Wi; nn.Upsample(scale_factor=2), mmvit4.py:243) of contiguous tensors
+ * (ld == C), one axis per pass (D, H, W) through `ws`: every incoming gradient is read once instead of once per input voxel that
+ * touches it.  Deterministic; per input voxel the outputs are summed in ascending order per axis.
+ * corrif_trilinear_bwd_sep_workspace: bytes of `ws`, or -1 when the geometry is not a pure up-sampling / too large. */
+int64_t corrif_trilinear_bwd_sep_workspace(int32_t B, int32_t C, int32_t Di, int32_t Hi, int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo);
+int corrif_trilinear_bwd_sep(const float* dy, float* dx, float* ws, int32_t B, int32_t C,
+                             int32_t Di, int32_t Hi, int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, void* stream);
 /* F.interpolate(size) default mode 'nearest' (mmvit4.py:271,276,281,286; aten::upsample_nearest3d) */
 int corrif_nearest_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t B, int32_t C,
                        int32_t Di, int32_t Hi, int32_t Wi, int32_t Do, int32_t Ho, int32_t Wo, void* stream);

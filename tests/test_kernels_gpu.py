@@ -551,6 +551,39 @@ def test_trilinear(ops, src, dst):
     assert rel(ncdhw(xg.grad), xr.grad) < 2e-6
 
 
+@pytest.mark.parametrize("src,dst,B,C", [((16, 16, 16), (32, 32, 32), 2, 16), ((8, 8, 8), (16, 16, 16), 3, 8), ((5, 9, 3), (11, 9, 12), 2, 4),
+                                          ((1, 4, 4), (6, 9, 8), 1, 12), ((7, 6, 5), (7, 6, 5), 2, 4)])
+def test_trilinear_adjoint_one_axis_per_pass(ops, src, dst, B, C):
+    """corrif_trilinear_bwd_sep (the decoder's up-samplings: D, H, W passes, every incoming gradient read once) against ATen's
+    upsample_trilinear3d_backward and against the one-pass gather, for x2 cubes, ragged ratios, a size-1 source axis and the identity;
+    through `ops.trilinear` the first case (>= 2^20 gradient elements) takes the same route (bit-identical result)."""
+    import corrif_hip as hip
+    x = rnd(B, C, *src, seed=1)
+    xr = x.clone().requires_grad_()
+    yr = F.interpolate(xr, size=dst, mode="trilinear", align_corners=True)
+    gy = rnd(*yr.shape, seed=2)
+    yr.backward(gy)
+    g = cl(gy).to(DEV)
+    need = hip.lib().corrif_trilinear_bwd_sep_workspace(B, C, *src, *dst)
+    assert need == 4 * B * C * (src[0] * dst[1] * dst[2] + src[0] * src[1] * dst[2])
+    ws = torch.empty(need // 4, device=DEV)
+    gx = torch.full((B, *src, C), float("nan"), device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert hip.lib().corrif_trilinear_bwd_sep(g.data_ptr(), gx.data_ptr(), ws.data_ptr(), B, C, *src, *dst, st) == 0
+    gg = torch.full((B, *src, C), float("nan"), device=DEV)
+    assert hip.lib().corrif_trilinear_bwd(g.data_ptr(), C, gg.data_ptr(), C, B, C, *src, *dst, st) == 0
+    torch.cuda.synchronize()
+    assert rel(ncdhw(gx), xr.grad) < 2e-6
+    assert rel(gx, gg) < 1e-6
+    # a down-sampling axis is refused (the gather handles it)
+    assert hip.lib().corrif_trilinear_bwd_sep_workspace(B, C, 9, 8, 8, 8, 16, 16) == -1
+    if gy.numel() >= (1 << 20):
+        xg = cl(x).to(DEV).requires_grad_()
+        ops.trilinear(xg, dst).backward(g)
+        torch.cuda.synchronize()
+        assert torch.equal(xg.grad, gx)
+
+
 def test_trilinear_scale2_equals_upsample(ops):
     x = rnd(1, 8, 16, 16, 16, seed=3)
     yr = torch.nn.Upsample(scale_factor=2, mode="trilinear", align_corners=True)(x)
