@@ -342,6 +342,8 @@ def main():
         model.auto_streams = os.environ["CORRIF_AUTO_STREAMS"] == "1"
     if os.environ.get("CORRIF_FLASH") is not None:           # A/B switch: 0 = materialised attention scores
         ops.FLASH_ATTENTION = os.environ["CORRIF_FLASH"] == "1"
+    if os.environ.get("CORRIF_SPLIT_BF16") is not None:      # A/B switch: 0 = the fp32-input MFMA main loop in every GEMM (rounds 1-3)
+        ops.SPLIT_BF16 = os.environ["CORRIF_SPLIT_BF16"] == "1"
     if os.environ.get("CORRIF_TRILINEAR_SEP") is not None:   # A/B switch: 0 = the up-samplings' adjoint as the one-pass gather
         ops.TRILINEAR_SEPARABLE = os.environ["CORRIF_TRILINEAR_SEP"] == "1"
     if os.environ.get("CORRIF_GROUPED") is not None:         # A/B switch: 0 = one Encoder.forward per modality (three launches per twin layer)

@@ -37,13 +37,13 @@ class Gemm(C.Structure):
                 ("addend2", ptr), ("ld_add2", i64),
                 ("bstats_x", ptr), ("bstats_ldx", i64), ("bstats_y", ptr), ("bstats_ldy", i64), ("bstats_mean", ptr), ("bstats_rstd", ptr),
                 ("zs_bias", i64), ("zs_add", i64), ("zs_add2", i64), ("zs_stats", i64), ("zs_bsx", i64), ("zs_bsy", i64), ("zs_bsstat", i64),
-                ("no_ksplit", i32)]
+                ("f32_mfma", i32)]
 
 
 class Wgrad(C.Structure):
     _fields_ = [("A", ptr), ("lda", i64), ("B", ptr), ("ldb", i64), ("Cs", i32), ("C", ptr), ("ldc", i64), ("ws", ptr),
                 ("R", i32), ("M", i32), ("N", i32), ("splits", i32), ("Z", i32), ("Zi", i32),
-                ("sA_o", i64), ("sA_i", i64), ("sB_o", i64), ("sB_i", i64), ("sC_o", i64), ("sC_i", i64), ("g", Geom)]
+                ("sA_o", i64), ("sA_i", i64), ("sB_o", i64), ("sB_i", i64), ("sC_o", i64), ("sC_i", i64), ("g", Geom), ("f32_mfma", i32)]
 
 
 class Conv3Patch(C.Structure):
@@ -166,7 +166,7 @@ def lib():
             fn = getattr(l, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if l.corrif_abi_version() != 6:
+        if l.corrif_abi_version() != 7:
             raise RuntimeError("corrif: ABI version mismatch")
         _lib = l
     return _lib

@@ -33,26 +33,33 @@ struct GemmCfg {
     static constexpr int SP = TN * 32 + 4;                       // epilogue staging row pitch (floats)
 };
 
-// KS ("K-split accumulation"): a long K loop accumulates in two levels - every KS_TILES K tiles (512 products) the running MFMA chain is
-// folded into a second accumulator set and restarted.  One fp32 fma chain over all of K loses accuracy like sqrt(K): measured per layer
-// against fp64 (tools/local_error.py, round 3) the forward / data-gradient error of this kernel was 1.0x ATen's at K <= 512, 1.9x at
-// 1024, 2.6x at 2048, 3.4x at 4096 and 4.5x at 4608-8640 (oneDNN's blocked accumulation stays flat) - the source of the HIP path's
-// systematically ~1.5x larger end-to-end gradient error.  Costs 16*TM*TN registers and ~1 % of the loop.
-#define KS_TILES 16
-template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL, bool KS = false>
+// SPLIT ("bf16x6"): the main loop of the 128-row tiles runs on the bf16 matrix cores with fp32-grade results.  While a tile is staged to
+// LDS every fp32 operand x is split EXACTLY into three bf16 terms x = h + m + l (round to nearest: 8 + 8 + 8 significand bits); the
+// product x*y is then the six bf16 products  hh' + (hm' + mh') + (hl' + mm' + lh')  accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The
+// three dropped terms ml' + lm' + ll' are <= 2^-25 |xy| - less than half an fp32 ulp of the product, i.e. less than what one fp32 fma
+// rounds away.  The leading products hh' accumulate in `acc`, the five small ones in a second accumulator that is folded in once at the
+// end, so the K sum sees ONE fp32 rounding per 16 products instead of 16: measured against fp64 (tools/split_lab.hip, full 24-bit random
+// operands) the relative L2 error is 0.36x that of the v_mfma_f32_32x32x2_f32 chain at K = 2304-4608 (3.1e-7 vs 8.6e-7) and the kernel is
+// 1.4-1.5x faster, because six 32-cycle bf16 MFMAs per K = 16 replace eight 64-cycle fp32-input MFMAs.  This also retires the two-level
+// "KS" accumulation of round 3 (the fp32 chain's sqrt(K) error growth was the source of the 1.5x end-to-end gradient-error excess).
+// LDS image: per operand three planes (h, m, l) of [rows][32 bf16], row pitch 80 B (20 dwords: 8 consecutive rows cover all 32 banks for
+// the ds_read_b128 fragment loads and for the 8-byte staging stores).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#define SPLIT_PB 80
+__device__ __forceinline__ void split3(const float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;          // exact
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);            // exact, and representable in 8 bits
+}
+template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL, int SPLIT = 0>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, const float* __restrict__ A, const float* __restrict__ B, float* lds,
                                               const int m0, const int n0, const int kt0, const int kt1,
                                               f32x16 (&acc)[BM / WM / 32][BN / WN / 32]) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    f32x16 tot[KS ? TM : 1][KS ? TN : 1];
-    if constexpr (KS) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
-    }
+    static_assert(!SPLIT || (VEC == 4 && BM == 128 && (BN == 128 || BN == 64)), "split-bf16 main loop: 128-row tiles of the float4 loader");
     constexpr int AI = BM / 32, BI = BN / 32;      // float4 chunks per thread per K tile
     constexpr int PBT = BN + 4;                           // row pitch of the K-major B tile (BL == 1)
     float* const As = lds;
@@ -174,8 +181,16 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, const float* __
             constexpr int CN = BN / 4;
 #pragma unroll
             for (int i = 0; i < BI; ++i) {
-                int cidx = tid + 256 * i;
-                int nc = cidx % CN, kk = cidx / CN;
+                int nc, kk;
+                if constexpr (SPLIT) {      // BI ADJACENT k rows per thread (transposed in registers at the LDS store), k group fastest across lanes
+                    constexpr int NG = BK / BI;
+                    nc = tid / NG;
+                    kk = (tid % NG) * BI + i;
+                } else {
+                    const int cidx = tid + 256 * i;
+                    nc = cidx % CN;
+                    kk = cidx / CN;
+                }
                 int kg = kt * BK + kk, n = n0 + nc * 4;
                 const bool ok = kg < p.K && n < p.N;
                 rb[i] = *reinterpret_cast<const f32x4*>(B + (ok ? (int64_t)kg * p.ldb + n : 0));
@@ -183,8 +198,55 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, const float* __
             }
         }
     };
+    // split-bf16 LDS image (bytes): A planes h, m, l ([BM][SPLIT_PB]) then B planes h, m, l ([BN][SPLIT_PB])
+    unsigned char* const Ab = reinterpret_cast<unsigned char*>(lds);
+    unsigned char* const Bb = Ab + 3 * BM * SPLIT_PB;
     auto store_tile = [&]() {
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (SPLIT) {
+            auto put4 = [&](unsigned char* base, int plane_bytes, int off, const f32x4 v) {      // 4 consecutive k of one row
+                bf16x4 h, m, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    __bf16 hh, mm, ll;
+                    split3(v[e], hh, mm, ll);
+                    h[e] = hh; m[e] = mm; l[e] = ll;
+                }
+                *reinterpret_cast<bf16x4*>(base + off) = h;
+                *reinterpret_cast<bf16x4*>(base + plane_bytes + off) = m;
+                *reinterpret_cast<bf16x4*>(base + 2 * plane_bytes + off) = l;
+            };
+#pragma unroll
+            for (int i = 0; i < AI; ++i) put4(Ab, BM * SPLIT_PB, (ar + 32 * i) * SPLIT_PB + kc * 8, (okA >> i) & 1 ? ra[i] : zero4);
+            if constexpr (BL == 0) {
+#pragma unroll
+                for (int i = 0; i < BI; ++i) put4(Bb, BN * SPLIT_PB, (ar + 32 * i) * SPLIT_PB + kc * 8, (okB >> i) & 1 ? rb[i] : zero4);
+            } else {
+                // [K][N] operand: this thread holds BI adjacent k rows x 4 columns; per column the BI values are one 2*BI-byte store
+                constexpr int NG = BK / BI;
+                const int nc = tid / NG, kgp = tid % NG;
+                f32x4 v[BI];
+#pragma unroll
+                for (int i = 0; i < BI; ++i) v[i] = (okB >> i) & 1 ? rb[i] : zero4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    __bf16 h[BI], m[BI], l[BI];
+#pragma unroll
+                    for (int i = 0; i < BI; ++i) split3(v[i][e], h[i], m[i], l[i]);
+                    const int off = (nc * 4 + e) * SPLIT_PB + kgp * BI * 2;
+                    if constexpr (BI == 4) {
+                        *reinterpret_cast<bf16x4*>(Bb + off) = bf16x4{h[0], h[1], h[2], h[3]};
+                        *reinterpret_cast<bf16x4*>(Bb + BN * SPLIT_PB + off) = bf16x4{m[0], m[1], m[2], m[3]};
+                        *reinterpret_cast<bf16x4*>(Bb + 2 * BN * SPLIT_PB + off) = bf16x4{l[0], l[1], l[2], l[3]};
+                    } else {
+                        *reinterpret_cast<bf16x2*>(Bb + off) = bf16x2{h[0], h[1]};
+                        *reinterpret_cast<bf16x2*>(Bb + BN * SPLIT_PB + off) = bf16x2{m[0], m[1]};
+                        *reinterpret_cast<bf16x2*>(Bb + 2 * BN * SPLIT_PB + off) = bf16x2{l[0], l[1]};
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(ar + 32 * i) * LDS_PITCH + kc * 4]) = (okA >> i) & 1 ? ra[i] : zero4;
         if constexpr (BL == 0) {
@@ -204,53 +266,87 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, const float* __
     };
 
     const int frow = lane & 31, fk = (lane >> 5) * 4;
+    // SPLIT == 2: the five small products of every element in their own accumulator (acc carries hh'); SPLIT == 1: all six in acc
+    // (the persistent stream-K kernel has no registers for a second set; its K sum still sees 6 roundings per 16 products instead of 16)
+    f32x16 sml[SPLIT == 2 ? TM : 1][SPLIT == 2 ? TN : 1];
+    if constexpr (SPLIT == 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sml[i][j][r] = 0.f;
+    }
     load_tile(kt0);
     for (int kt = kt0; kt < kt1; ++kt) {
         store_tile();
         __syncthreads();
         if (kt + 1 < kt1) load_tile(kt + 1);      // global loads fly while the MFMAs run
+        if constexpr (SPLIT) {
+            const int fb = (lane >> 5) * 16;      // byte offset of this lane's 8 k inside a 16-deep slab (lane (r, h): k = 8h .. 8h+7)
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const f32x4*>(&As[((wm * TM + i) * 32 + frow) * LDS_PITCH + kk * 8 + fk]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if constexpr (BL == 0) {
-                    b[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * TN + j) * 32 + frow) * LDS_PITCH + kk * 8 + fk]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) b[j][e] = Bs[(kk * 8 + fk + e) * PBT + (wn * TN + j) * 32 + frow];
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                bf16x8 a[TM][3], b[TN][3];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-        }
-        if constexpr (KS) {
-            if (((kt - kt0) & (KS_TILES - 1)) == KS_TILES - 1 && kt + 1 < kt1) {      // fold the chain into the second level, restart it
+                    for (int q = 0; q < 3; ++q)
+                        a[i][q] = *reinterpret_cast<const bf16x8*>(Ab + q * BM * SPLIT_PB + ((wm * TM + i) * 32 + frow) * SPLIT_PB + kk * 32 + fb);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        b[j][q] = *reinterpret_cast<const bf16x8*>(Bb + q * BN * SPLIT_PB + ((wn * TN + j) * 32 + frow) * SPLIT_PB + kk * 32 + fb);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        tot[i][j] += acc[i][j];
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                        f32x16 t = SPLIT == 2 ? sml[i][j] : acc[i][j];
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], t, 0, 0, 0);      // l h'
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], t, 0, 0, 0);      // h l'
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], t, 0, 0, 0);      // m m'
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], t, 0, 0, 0);      // m h'
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], t, 0, 0, 0);      // h m'
+                        if constexpr (SPLIT == 2) {
+                            sml[i][j] = t;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);      // h h'
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], t, 0, 0, 0);
+                        }
                     }
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                f32x4 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a[i] = *reinterpret_cast<const f32x4*>(&As[((wm * TM + i) * 32 + frow) * LDS_PITCH + kk * 8 + fk]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (BL == 0) {
+                        b[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * TN + j) * 32 + frow) * LDS_PITCH + kk * 8 + fk]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) b[j][e] = Bs[(kk * 8 + fk + e) * PBT + (wn * TN + j) * 32 + frow];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
             }
         }
         __syncthreads();
     }
-    if constexpr (KS) {
+    if constexpr (SPLIT == 2) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] += tot[i][j];
+            for (int j = 0; j < TN; ++j) acc[i][j] += sml[i][j];
     }
 }
 
@@ -394,12 +490,13 @@ struct GemmLds {
     static constexpr int B_FLOATS = BL == 0 ? BN * LDS_PITCH : BK * PBT;
     // one LDS array: [A tile | B tile] during the K loop, re-used as the per-wave output staging area in the epilogue
     static constexpr int FLOATS = BM * LDS_PITCH + B_FLOATS > 4 * 32 * SP ? BM * LDS_PITCH + B_FLOATS : 4 * 32 * SP;
+    static constexpr int SPLIT_FLOATS = 3 * (BM + BN) * SPLIT_PB / 4 > 4 * 32 * SP ? 3 * (BM + BN) * SPLIT_PB / 4 : 4 * 32 * SP;
 };
 
-template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL, bool KS = false>
-__global__ __launch_bounds__(256, KS ? 2 : 1) void gemm_fwd_kernel(GemmArgs p) {
+template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL, int SPLIT = 0>
+__global__ __launch_bounds__(256, SPLIT ? 2 : 1) void gemm_fwd_kernel(GemmArgs p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    __shared__ __attribute__((aligned(16))) float lds[GemmLds<BM, BN, WM, WN, BL>::FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[SPLIT ? GemmLds<BM, BN, WM, WN, BL>::SPLIT_FLOATS : GemmLds<BM, BN, WM, WN, BL>::FLOATS];
     const uint32_t tiles_n = (p.N + BN - 1) / BN;
     const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
@@ -414,17 +511,17 @@ __global__ __launch_bounds__(256, KS ? 2 : 1) void gemm_fwd_kernel(GemmArgs p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    gemm_mainloop<BM, BN, WM, WN, VEC, GEMM, BL, KS>(p, A, B, lds, m0, n0, 0, (p.K + BK - 1) / BK, acc);
+    gemm_mainloop<BM, BN, WM, WN, VEC, GEMM, BL, SPLIT>(p, A, B, lds, m0, n0, 0, (p.K + BK - 1) / BK, acc);
     gemm_epilogue<BM, BN, WM, WN>(p, C, lds, m0, n0, acc, zo);
 }
 
 // unit boundary of stream-K workgroup g: floor(g * U / G)
 __device__ __forceinline__ int64_t sk_bound(int64_t g, int64_t U, int G) { return g * U / G; }
 
-template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL, bool KS = false>
-__global__ __launch_bounds__(256) void gemm_sk_kernel(GemmArgs p) {
+template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL, int SPLIT = 0>
+__global__ __launch_bounds__(256, SPLIT ? 2 : 1) void gemm_sk_kernel(GemmArgs p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    __shared__ __attribute__((aligned(16))) float lds[GemmLds<BM, BN, WM, WN, BL>::FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[SPLIT ? GemmLds<BM, BN, WM, WN, BL>::SPLIT_FLOATS : GemmLds<BM, BN, WM, WN, BL>::FLOATS];
     const int G = (int)gridDim.x;
     const int g = (int)xcd_remap(blockIdx.x, gridDim.x);      // neighbouring ranges (shared operand panels) on one XCD's L2
     const int nk = p.sk_nk;
@@ -448,7 +545,7 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(GemmArgs p) {
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        gemm_mainloop<BM, BN, WM, WN, VEC, GEMM, BL, KS>(p, A, B, lds, m0, n0, k0, k1, acc);
+        gemm_mainloop<BM, BN, WM, WN, VEC, GEMM, BL, SPLIT>(p, A, B, lds, m0, n0, k0, k1, acc);
         if (k0 == 0 && k1 == nk) {
             gemm_epilogue<BM, BN, WM, WN>(p, p.C + zo * p.sC_o + zi * p.sC_i, lds, m0, n0, acc, zo);
             __syncthreads();                                  // the staging area is the next piece's A/B tile
@@ -548,37 +645,38 @@ static int sk_plan(int64_t tiles_total, int nk, int slots) {
 
 template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL>
 static int launch_variant(GemmArgs& a, int Z, hipStream_t s, bool plan_only, size_t* ws_bytes) {
-    // stream-K exists for the two tiles that carry the long-K shapes (128x128, 128x64, float4 loader); the two-level K accumulation for
-    // every float4 tile (the small ones run the small-batch parity cases)
+    // stream-K and the split-bf16 main loop exist for the two tiles that carry the encoder's shapes (128x128, 128x64, float4 loader)
     constexpr bool BIG = VEC == 4 && BM == 128 && (BN == 128 || BN == 64);
-    constexpr bool KSV = VEC == 4;
     const int64_t tiles_mn = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int nk = (a.K + BK - 1) / BK;
+    const bool split = BIG && !a.f32_mfma;
     int G = 0;
     if constexpr (BIG) {
-        static int per_cu = 0;
-        if (!per_cu) per_cu = resident_per_cu(gemm_sk_kernel<BM, BN, WM, WN, VEC, GEMM, BL, false>);
-        G = a.sk_allowed ? sk_plan(tiles_mn * Z, nk, num_cus() * per_cu) : 0;
+        static int per_cu[2] = {0, 0};
+        if (!per_cu[0]) per_cu[0] = resident_per_cu(gemm_sk_kernel<BM, BN, WM, WN, VEC, GEMM, BL, 0>);
+        if (!per_cu[1]) per_cu[1] = resident_per_cu(gemm_sk_kernel<BM, BN, WM, WN, VEC, GEMM, BL, 1>);
+        G = a.sk_allowed ? sk_plan(tiles_mn * Z, nk, num_cus() * per_cu[split ? 1 : 0]) : 0;
     }
     if (ws_bytes) *ws_bytes = G ? (size_t)2 * G * BM * BN * sizeof(float) : 0;
     if (plan_only) return CORRIF_OK;
     if (G && !a.sk_ws) return CORRIF_EINVAL;                  // the caller did not provide the workspace corrif_gemm_fwd_workspace asked for
     if (!G) {
         dim3 grid((uint32_t)tiles_mn, 1, Z);
-        if constexpr (KSV) {
-            if (nk >= 2 * KS_TILES && !a.ks_off) {            // K >= 1024: two-level accumulation
-                hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC, GEMM, BL, true>), grid, dim3(256), 0, s, a);
+        if constexpr (BIG) {
+            if (split) {
+                hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC, GEMM, BL, 2>), grid, dim3(256), 0, s, a);
                 CORRIF_CHECK_LAUNCH();
                 return CORRIF_OK;
             }
         }
-        hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC, GEMM, BL, false>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC, GEMM, BL, 0>), grid, dim3(256), 0, s, a);
         CORRIF_CHECK_LAUNCH();
         return CORRIF_OK;
     }
     if constexpr (BIG) {
         a.sk_G = G; a.sk_nk = nk; a.sk_tiles_mn = (int)tiles_mn; a.sk_tiles = (int)(tiles_mn * Z);
-        hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, WM, WN, VEC, GEMM, BL, false>), dim3(G), dim3(256), 0, s, a);
+        if (split) hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, WM, WN, VEC, GEMM, BL, 1>), dim3(G), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, WM, WN, VEC, GEMM, BL, 0>), dim3(G), dim3(256), 0, s, a);
         CORRIF_CHECK_LAUNCH();
         hipLaunchKernelGGL((gemm_sk_fixup_kernel<BM, BN, WM, WN>), dim3(G - 1), dim3(256), 0, s, a);
         CORRIF_CHECK_LAUNCH();
@@ -651,7 +749,7 @@ static int gemm_fwd_impl(const CorrifGemm* p, void* stream, bool plan_only, size
     a.om_d = p->om_d; a.om_h = p->om_h; a.om_w = p->om_w; a.oo_d = p->oo_d; a.oo_h = p->oo_h; a.oo_w = p->oo_w;
     a.sk_ws = p->ws; a.sk_G = 0; a.sk_nk = 0; a.sk_tiles = 0; a.sk_tiles_mn = 0;
     a.sk_allowed = p->no_split ? 0 : 1;
-    a.ks_off = p->no_ksplit ? 1 : 0;
+    a.f32_mfma = p->f32_mfma ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const int Z = p->Z;
     if (scalar) return launch_fwd<128, 64, 2, 2, 1>(a, Z, s, plan_only, ws_bytes);
@@ -852,6 +950,188 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same contraction on the bf16 matrix cores (SPLIT, see gemm_mainloop): both operands are contracted over their ROWS, so the
+// bf16 fragments (8 consecutive r per lane) need the tiles transposed: a thread loads AI (BI) ADJACENT rows of one float4 column
+// chunk, splits them, and stores per column the AI values as one 2*AI-byte piece of the [column][r] plane - the transposition costs no
+// instruction, only the choice of which registers go into one store.  Row group is the fastest index across lanes: 16 (8) lanes fill
+// one 64-byte LDS row, so the stores are conflict-free; the global loads are 64-byte pieces of 16 (8) different rows per wave.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool GEMM>
+__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int CA = BM / 4, CB = BN / 4;            // float4 chunks per row
+    constexpr int AI = 32 * CA / 256, BI = 32 * CB / 256;      // adjacent rows per thread (2 for a 64-wide operand, 4 for 128)
+    static_assert(AI >= 2 && BI >= 2, "tile too small for the transposing store");
+    constexpr int NGA = 32 / AI, NGB = 32 / BI;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * (BM + BN) * SPLIT_PB];
+    unsigned char* const Ab = lds;
+    unsigned char* const Bb = lds + 3 * BM * SPLIT_PB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const uint32_t tiles_n = (p.N + BN - 1) / BN;
+    const uint32_t tiles_mn = ((p.M + BM - 1) / BM) * tiles_n;
+    const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t zz = lin / tiles_mn, tile = lin - zz * tiles_mn;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    int split = 0, z = 0;
+    if (p.splits > 1) { z = (int)zz / p.splits; split = (int)zz - z * p.splits; } else z = (int)zz;
+    const int zo = z / p.Zi, zi = z - zo * p.Zi;
+    const float* __restrict__ A = p.A + zo * p.sA_o + zi * p.sA_i;
+    const float* __restrict__ B = p.B + zo * p.sB_o + zi * p.sB_i;
+    const int r_begin = split * p.rows_per_split;
+    const int r_end = min(p.R, r_begin + p.rows_per_split);
+
+    const int jc = tid / NGB, bg = tid % NGB;          // B: column chunk jc, rows bg * BI + i
+    const int j = n0 + jc * 4;
+    const bool jin = j < p.N;
+    int td = 0, th = 0, tw = 0, cch = j;
+    if (!GEMM && jin) {
+        const int tap = j / p.Cs;
+        cch = j - tap * p.Cs;
+        td = (int)fdiv((uint32_t)tap, p.g.dKhw);
+        const int rem = tap - td * (int)p.g.dKhw.d;
+        th = (int)fdiv((uint32_t)rem, p.g.dKw);
+        tw = rem - th * (int)p.g.dKw.d;
+    }
+    const int ac = tid / NGA, ag = tid % NGA;          // A: column chunk ac, rows ag * AI + i
+    const int am = m0 + ac * 4;
+    const bool ain = am < p.M;
+
+    f32x16 acc[TM][TN], sml[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][jj][r] = 0.f; sml[i][jj][r] = 0.f; }
+
+    f32x4 ra[AI], rb[BI];
+    uint32_t okA = 0, okB = 0;
+    auto load_tile = [&](int r0) {
+        okA = okB = 0;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int row = r0 + ag * AI + i;
+            const bool ok = ain && row < r_end;
+            ra[i] = *reinterpret_cast<const f32x4*>(A + (ok ? (int64_t)row * p.lda + am : 0));
+            okA |= (uint32_t)ok << i;
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int row = r0 + bg * BI + i;
+            const bool rin = jin && row < r_end;
+            if constexpr (GEMM) {
+                rb[i] = *reinterpret_cast<const f32x4*>(B + (rin ? (int64_t)row * p.ldb + j : 0));
+                okB |= (uint32_t)rin << i;
+            } else {
+                uint32_t n, pk;
+                int vox;
+                decode_row((uint32_t)(rin ? row : 0), p.g, n, pk);
+                const bool ok = gather_voxel(pk, td, th, tw, p.g, vox) && rin;
+                rb[i] = *reinterpret_cast<const f32x4*>(B + (ok ? (int64_t)n * p.g.sample_pitch + (int64_t)vox * p.ldb + cch : 0));
+                okB |= (uint32_t)ok << i;
+            }
+        }
+    };
+    auto put = [&](unsigned char* base, const int plane_bytes, const int off, const float (&v)[4]) {
+        __bf16 h[4], m[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split3(v[i], h[i], m[i], l[i]);
+        *reinterpret_cast<bf16x4*>(base + off) = bf16x4{h[0], h[1], h[2], h[3]};
+        *reinterpret_cast<bf16x4*>(base + plane_bytes + off) = bf16x4{m[0], m[1], m[2], m[3]};
+        *reinterpret_cast<bf16x4*>(base + 2 * plane_bytes + off) = bf16x4{l[0], l[1], l[2], l[3]};
+    };
+    auto put2 = [&](unsigned char* base, const int plane_bytes, const int off, const float (&v)[2]) {
+        __bf16 h[2], m[2], l[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) split3(v[i], h[i], m[i], l[i]);
+        *reinterpret_cast<bf16x2*>(base + off) = bf16x2{h[0], h[1]};
+        *reinterpret_cast<bf16x2*>(base + plane_bytes + off) = bf16x2{m[0], m[1]};
+        *reinterpret_cast<bf16x2*>(base + 2 * plane_bytes + off) = bf16x2{l[0], l[1]};
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int off = (ac * 4 + e) * SPLIT_PB + ag * AI * 2;
+            if constexpr (AI == 4) {
+                const float v[4] = {(okA & 1) ? ra[0][e] : 0.f, (okA & 2) ? ra[1][e] : 0.f, (okA & 4) ? ra[2][e] : 0.f, (okA & 8) ? ra[3][e] : 0.f};
+                put(Ab, BM * SPLIT_PB, off, v);
+            } else {
+                const float v[2] = {(okA & 1) ? ra[0][e] : 0.f, (okA & 2) ? ra[1][e] : 0.f};
+                put2(Ab, BM * SPLIT_PB, off, v);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int off = (jc * 4 + e) * SPLIT_PB + bg * BI * 2;
+            if constexpr (BI == 4) {
+                const float v[4] = {(okB & 1) ? rb[0][e] : 0.f, (okB & 2) ? rb[1][e] : 0.f, (okB & 4) ? rb[2][e] : 0.f, (okB & 8) ? rb[3][e] : 0.f};
+                put(Bb, BN * SPLIT_PB, off, v);
+            } else {
+                const float v[2] = {(okB & 1) ? rb[0][e] : 0.f, (okB & 2) ? rb[1][e] : 0.f};
+                put2(Bb, BN * SPLIT_PB, off, v);
+            }
+        }
+    };
+
+    const int frow = lane & 31, fb = (lane >> 5) * 16;
+    if (r_begin < r_end) {
+        load_tile(r_begin);
+        for (int r0 = r_begin; r0 < r_end; r0 += 32) {
+            store_tile();
+            __syncthreads();
+            if (r0 + 32 < r_end) load_tile(r0 + 32);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        a[i][q] = *reinterpret_cast<const bf16x8*>(Ab + q * BM * SPLIT_PB + ((wm * TM + i) * 32 + frow) * SPLIT_PB + kk * 32 + fb);
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        b[jj][q] = *reinterpret_cast<const bf16x8*>(Bb + q * BN * SPLIT_PB + ((wn * TN + jj) * 32 + frow) * SPLIT_PB + kk * 32 + fb);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj) {
+                        f32x16 t = sml[i][jj];
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[jj][0], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[jj][2], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[jj][1], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[jj][0], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[jj][1], t, 0, 0, 0);
+                        sml[i][jj] = t;
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[jj][0], acc[i][jj], 0, 0, 0);
+                    }
+            }
+            __syncthreads();
+        }
+    }
+
+    float* __restrict__ C;
+    int64_t ldc;
+    if (p.splits > 1) { C = p.ws + ((int64_t)z * p.splits + split) * p.M * p.N; ldc = p.N; }
+    else { C = p.C + zo * p.sC_o + zi * p.sC_i; ldc = p.ldc; }
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj) {
+        const int col = n0 + (wn * TN + jj) * 32 + (lane & 31);
+        if (col >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < p.M) C[(int64_t)row * ldc + col] = acc[i][jj][r] + sml[i][jj][r];
+            }
+    }
+}
+
 // out[i] = sum_j ws[j*n + i] in a fixed order: block = 64 consecutive elements x 4 slab lanes (coalesced 256-B rows)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t n, int count,
                                                           int N, int64_t ldc, int64_t out_zstride) {
@@ -883,8 +1163,10 @@ static int pick_splits(int R, int M, int N, int BM, int BN, int Z) {
     int64_t maxs = R / 256;                 // at least 8 K-tiles of work per split
     if (maxs < 1) maxs = 1;
     if (maxs > 4096) maxs = 4096;
-    const int64_t slots = 5 * 256;
-    const double t_full = 2.0 * R * (double)M * N / 85e12, t_slab = 2.0 * (double)M * N * 4.0 / 3e12;
+    // the split-bf16 kernels (BM >= 64) hold 46 KB of LDS: 3 workgroups per CU at ~120 TFLOP/s; the fp32-input ones 5 at ~85
+    const bool split = BM >= 64;
+    const int64_t slots = (split ? 3 : 5) * 256;
+    const double t_full = 2.0 * R * (double)M * N / (split ? 120e12 : 85e12), t_slab = 2.0 * (double)M * N * 4.0 / 3e12;
     int64_t best = 1;
     double best_t = 1e30;
     for (int64_t sp = 1; sp <= maxs && (sp == 1 || sp * tiles <= 6 * slots); ++sp) {
@@ -958,11 +1240,17 @@ extern "C" int corrif_wgrad(const CorrifWgrad* p, void* stream) {
         int rc = launch_smallm_wgrad(a, (int)nz, s);
         if (rc != CORRIF_OK) return rc;
     } else if (BM == 128 && BN == 64) {
-        if (a.g.is_gemm) hipLaunchKernelGGL((wgrad_kernel<128, 64, 4, 1, 4, true>), grid, dim3(256), 0, s, a);
+        if (!p->f32_mfma) {
+            if (a.g.is_gemm) hipLaunchKernelGGL((wgrad_split_kernel<128, 64, 4, 1, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((wgrad_split_kernel<128, 64, 4, 1, false>), grid, dim3(256), 0, s, a);
+        } else if (a.g.is_gemm) hipLaunchKernelGGL((wgrad_kernel<128, 64, 4, 1, 4, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_kernel<128, 64, 4, 1, 4, false>), grid, dim3(256), 0, s, a);
     } else if (BM == 32) {
         if (a.g.is_gemm) hipLaunchKernelGGL((wgrad_kernel<32, 128, 1, 4, 4, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_kernel<32, 128, 1, 4, 4, false>), grid, dim3(256), 0, s, a);
+    } else if (!p->f32_mfma) {
+        if (a.g.is_gemm) hipLaunchKernelGGL((wgrad_split_kernel<64, 128, 2, 2, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wgrad_split_kernel<64, 128, 2, 2, false>), grid, dim3(256), 0, s, a);
     } else {
         if (a.g.is_gemm) hipLaunchKernelGGL((wgrad_kernel<64, 128, 2, 2, 4, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_kernel<64, 128, 2, 2, 4, false>), grid, dim3(256), 0, s, a);

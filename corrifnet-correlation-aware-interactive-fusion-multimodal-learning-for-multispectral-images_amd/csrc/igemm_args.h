@@ -24,7 +24,7 @@ struct GemmArgs {
     // grouped launches (Z = the three modality encoders' identical-shape layers in ONE launch): per OUTER batch index zo the epilogue
     // operands move by these strides (floats; zs_stats in doubles)
     int64_t zs_bias, zs_add, zs_add2, zs_stats, zs_bsx, zs_bsy, zs_bsstat;
-    int ks_off;         // diagnostics: 1 = one fma chain over all of K even when K >= 1024 (see KS in igemm.hip)
+    int f32_mfma;       // 1 = the v_mfma_f32_32x32x2_f32 main loop even where the split-bf16 loop exists (A/B, see SPLIT in igemm.hip)
 };
 
 

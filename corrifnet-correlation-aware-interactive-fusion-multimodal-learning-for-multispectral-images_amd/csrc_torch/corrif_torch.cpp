@@ -81,7 +81,7 @@ at::Tensor repack(const at::Tensor& src, at::IntArrayRef shape_out, int O, int I
 
 void launch_gemm(CorrifGemm& g) {
     g.no_split = 1;
-    g.no_ksplit = 1;
+    g.f32_mfma = 0;
     chk(corrif_gemm_fwd(&g, cur_stream()), "corrif_gemm_fwd");
 }
 

@@ -44,7 +44,7 @@ def tl():
 
 def _fast():
     """the TORCH_LIBRARY ops serve this call: no autograd graph is being recorded and the kernel-variant switches are at their defaults"""
-    return USE_TORCH_LIBRARY and not torch.is_grad_enabled() and not (STREAM_K or STREAM_K_LONG or K_SPLIT_ACCUM) and USE_PATCH and \
+    return USE_TORCH_LIBRARY and not torch.is_grad_enabled() and not (STREAM_K or STREAM_K_LONG) and SPLIT_BF16 and USE_PATCH and \
         USE_STEM_KERNEL and PATCH_STATS
 
 
@@ -99,12 +99,11 @@ STREAM_K_LONG = False     # measured (round 2): wall-neutral on the B=32 step (2
 # (K <= 1024); on the B=32 step it is worth 0.8 ms of 254 (A/B, one box) - and it re-associates the K sum, so the grouped schedule would
 # no longer be bit-identical to the per-modality one.  Off: the two encoder schedules produce the same bits (tests/test_model_gpu.py).
 STREAM_K_GROUPED = False
-# Two-level K accumulation of the forward / data-gradient GEMMs (CorrifGemm.no_ksplit = 0): a fresh fma chain every 512 products.  One
-# chain over all of K has 1.9x (K = 1024) ... 4.5x (K = 4608-8640) ATen's local error against fp64 (tools/local_error.py; oneDNN
-# accumulates in blocks), with it the kernels sit at ATen's level - at 7-9 % of the long-K launches' time (the second accumulator set
-# costs a wave of occupancy; tools/group_microbench.py), 1.7 % of the step.  Both are 4x inside the per-kernel bar (2e-6 forward) and the
-# end-to-end brackets do not move (tools/grad_diag.py: median gradient-error ratio 0.94 vs 0.95), so the default is the fast one.
-K_SPLIT_ACCUM = False
+# Main loop of the GEMM family's 128-row tiles (CorrifGemm.f32_mfma / CorrifWgrad.f32_mfma = 0): fp32 operands split exactly into three
+# bf16 terms at the LDS store, six bf16 MFMA products per fp32 product, fp32 accumulation (csrc/igemm.hip "SPLIT").  Against fp64 the
+# result is MORE accurate than the fp32-input MFMA chain it replaces (one rounding per 16 products of the K sum instead of 16: 0.36x the
+# error at K = 2304-4608, tools/split_lab.hip) and 1.4-1.5x faster.  False = v_mfma_f32_32x32x2_f32 everywhere (rounds 1-3; A/B).
+SPLIT_BF16 = True
 
 
 def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, addend=None, ld_add=0, act=ACT_NONE,
@@ -141,7 +140,7 @@ def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, add
     buf = None
     sk = STREAM_K or (STREAM_K_LONG and K >= 2048 and Z == 1 and M * N <= 128 * 128 * 512) or (STREAM_K_GROUPED and zs is not None and K >= 2048)
     g.no_split = 0 if sk else 1
-    g.no_ksplit = 0 if K_SPLIT_ACCUM else 1
+    g.f32_mfma = 0 if SPLIT_BF16 else 1
     if sk:
         nws = lib().corrif_gemm_fwd_workspace(g)      # stream-K split: slabs for the tiles a share boundary cuts
         if nws:
@@ -175,6 +174,7 @@ def wgrad(A, lda, Bm, ldb, Cs, Cout, ldc, R, M, N, geom, dev, Z=1, Zi=1, sA=(0, 
     w.sB_o, w.sB_i = sB
     w.sC_o, w.sC_i = sC
     w.g = geom
+    w.f32_mfma = 0 if SPLIT_BF16 else 1
     if Z > 1:                   # grouped weight gradient (Zi = 1): row splits per group; batched attention products (Zi > 1): none
         w.splits = lib().corrif_wgrad_plan(R, M, N, Z) if Zi == 1 else 1
     else:

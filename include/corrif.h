@@ -32,7 +32,7 @@ extern "C" {
 #define CORRIF_EUNSUPPORTED (-2)
 #define CORRIF_ELAUNCH (-3)
 
-#define CORRIF_ABI_VERSION 6   /* 6: grouped launches (CorrifGemm.zs_*, corrif_wgrad with Z x splits, per-group affine norms)  2: CorrifConv3Patch.fold  3: CorrifGemm.ws / no_split (stream-K), corrif_scale, corrif_fill  4: CorrifGemm.addend2, corrif_flash_attn_*  5: CorrifGemm.bstats_*, corrif_norm_bwd_pre, corrif_stem_*, corrif_depth_* */
+#define CORRIF_ABI_VERSION 7   /* 7: split-bf16 main loops (CorrifGemm.f32_mfma replaces no_ksplit, CorrifWgrad.f32_mfma), corrif_trilinear_bwd_sep  6: grouped launches (CorrifGemm.zs_*, corrif_wgrad with Z x splits, per-group affine norms)  2: CorrifConv3Patch.fold  3: CorrifGemm.ws / no_split (stream-K), corrif_scale, corrif_fill  4: CorrifGemm.addend2, corrif_flash_attn_*  5: CorrifGemm.bstats_*, corrif_norm_bwd_pre, corrif_stem_*, corrif_depth_* */
 int corrif_abi_version(void);
 /* name of the gfx target the library was built for ("gfx950") - host-only call */
 const char* corrif_build_arch(void);
@@ -118,9 +118,11 @@ typedef struct CorrifGemm {
      * per outer batch index (floats; zs_stats in doubles): bias, addend, addend2, stats_part, bstats_x, bstats_y, bstats_mean / _rstd.
      * With Z > 1 the fused statistics are per group: stats_rows_per_group must equal M. */
     int64_t zs_bias, zs_add, zs_add2, zs_stats, zs_bsx, zs_bsy, zs_bsstat;
-    /* K >= 1024 accumulates in two levels (a fresh fma chain every 512 products, folded into a second accumulator set): one chain over all
-     * of K loses accuracy like sqrt(K) (3-4x ATen's error at K = 4608, tools/local_error.py).  no_ksplit = 1 restores the single chain (A/B). */
-    int32_t no_ksplit;
+    /* Main loop of the 128-row tiles (the encoder's shapes): by default every fp32 operand is split exactly into three bf16 terms while it
+     * is staged and the product is formed from six bf16 MFMA products with fp32 accumulation ("bf16x6": dropped terms <= 2^-25 |xy|; one
+     * fp32 rounding per 16 products of the K sum - 0.36x the error of the fp32-input MFMA chain against fp64 at K = 2304-4608, and
+     * 1.4-1.5x its speed; csrc/igemm.hip, tools/split_lab.hip).  f32_mfma = 1 selects the v_mfma_f32_32x32x2_f32 loop instead (A/B). */
+    int32_t f32_mfma;
 } CorrifGemm;
 int corrif_gemm_fwd(const CorrifGemm* p, void* stream);
 size_t corrif_gemm_fwd_workspace(const CorrifGemm* p);   /* bytes of CorrifGemm.ws this launch needs; queries the device's CU count */
@@ -150,6 +152,7 @@ typedef struct CorrifWgrad {
     int32_t R, M, N; int32_t splits;
     int32_t Z, Zi; int64_t sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;   /* batch; splits > 1 with Z > 1 (ABI 6): ws holds Z*splits slabs */
     CorrifGeom g;                                 /* rows = R enumerate g.R*, source = B     */
+    int32_t f32_mfma;                             /* ABI 7: 1 = the fp32-input MFMA loop instead of the split-bf16 one (see CorrifGemm.f32_mfma) */
 } CorrifWgrad;
 int corrif_wgrad(const CorrifWgrad* p, void* stream);
 size_t corrif_wgrad_workspace(const CorrifWgrad* p);   /* bytes; host-only */

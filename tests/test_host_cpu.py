@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(built):
     assert set(corrif_hip.EXPORTS) == declared           # the ctypes mirror binds exactly the header's surface
     # host-only entry points are callable without a GPU
     lib.corrif_abi_version.restype = ctypes.c_int
-    assert lib.corrif_abi_version() == 6
+    assert lib.corrif_abi_version() == 7
     lib.corrif_build_arch.restype = ctypes.c_char_p
     assert lib.corrif_build_arch() == b"gfx950"
     lib.corrif_wgrad_plan.restype = ctypes.c_int

@@ -294,23 +294,30 @@ def test_grouped_batch_norm_equals_its_twins(ops, relu_in, relu_out, res, C, tra
         assert rel(rmg[g], rm) < 1e-6 and rel(rvg[g], rv) < 1e-6
 
 
-def test_k_split_accumulation_reaches_the_reference_arithmetics_error(ops, monkeypatch):
-    """ops.K_SPLIT_ACCUM: a long-K convolution (1x3x3, 512 channels: K = 4608) against fp64.  One fma chain over all of K sits at
-    4-5x the local error of stock ATen on the CPU (blocked accumulation, = the reference's arithmetic); with the two-level
-    accumulation (a fresh chain every 512 products) it is within 2x of ATen's.  Both are far inside the per-kernel bar."""
-    Ci, Co, k, pad, B, D, Hh, W = 512, 64, (1, 3, 3), (0, 1, 1), 2, 2, 6, 6
-    x, w = rnd(B, Ci, D, Hh, W, seed=1), rnd(Co, Ci, *k, seed=2, scale=(Ci * 9) ** -0.5)
-    truth = F.conv3d(x.double(), w.double(), None, 1, pad)
-    e_aten = rel(F.conv3d(x, w, None, 1, pad), truth)
-    errs = {}
-    for on in (False, True):
-        monkeypatch.setattr(ops, "K_SPLIT_ACCUM", on)
-        y = ops.conv3d(cl(x).to(DEV), w.to(DEV), None, (1, 1, 1), pad)
-        torch.cuda.synchronize()
-        errs[on] = rel(ncdhw(y), truth)
-    assert errs[True] < 2e-6 and errs[False] < 2e-6
-    assert errs[True] <= 2.2 * e_aten, (errs, e_aten)            # measured: 4.2e-7 vs ATen's 2.2e-7 (the 512-product chains), 1.1e-6 without
-    assert errs[True] < 0.6 * errs[False], (errs, e_aten)
+def test_split_bf16_main_loop_is_at_least_as_accurate_as_the_fp32_mfma_chain(ops, monkeypatch):
+    """ops.SPLIT_BF16 (default): the 128-row tiles form every fp32 product from six bf16 MFMA products of exactly split operands
+    (csrc/igemm.hip SPLIT).  A long-K convolution on the 128x128 tile (3x3x3... 1x3x3, 128 channels, 25088 rows: K = 1152) and a 1x1 with
+    K = 2048 against fp64: the split loop must be inside the per-kernel bar and no worse than the v_mfma_f32_32x32x2_f32 chain it replaces
+    (measured 0.4-0.8x its error: one fp32 rounding per 16 products of the K sum instead of 16), forward, data gradient and weight gradient."""
+    cases = [(128, 128, (1, 3, 3), (0, 1, 1), (2, 4, 56, 56)), (2048, 256, (1, 1, 1), (0, 0, 0), (2, 4, 56, 56))]
+    for Ci, Co, k, pad, (B, D, Hh, W) in cases:
+        x, w = rnd(B, Ci, D, Hh, W, seed=1), rnd(Co, Ci, *k, seed=2, scale=(Ci * k[1] * k[2]) ** -0.5)
+        gy = rnd(B, Co, D, Hh, W, seed=3)
+        x64, w64 = x.double().to(DEV).requires_grad_(), w.double().to(DEV).requires_grad_()
+        with torch.backends.cudnn.flags(enabled=False):
+            truth = F.conv3d(x64, w64, None, 1, pad)
+            truth.backward(gy.double().to(DEV))
+        errs = {}
+        for on in (False, True):
+            monkeypatch.setattr(ops, "SPLIT_BF16", on)
+            xg, wg = cl(x).to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+            y = ops.conv3d(xg, wg, None, (1, 1, 1), pad)
+            y.backward(cl(gy).to(DEV))
+            torch.cuda.synchronize()
+            errs[on] = (rel(ncdhw(y), truth), rel(ncdhw(xg.grad), x64.grad), rel(wg.grad, w64.grad))
+        for e_split, e_f32 in zip(errs[True], errs[False]):
+            assert e_split < 2e-6 and e_f32 < 2e-6, errs
+            assert e_split <= 1.05 * e_f32, errs
 
 
 def test_conv3d_sliced_io(ops):

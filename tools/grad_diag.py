@@ -39,7 +39,7 @@ def oracle(case, dtype, sd):
 
 def hip(case, sd, serial, stream_k, tap=True, patch=True, bwd_stats=True, splits_r1=False, stem=True, compact=True, ksplit=True, grouped=True):
     ops.STREAM_K, ops.USE_PATCH, mmvit4.GRAD_TAP = stream_k, patch, tap
-    ops.K_SPLIT_ACCUM = ksplit
+    ops.SPLIT_BF16 = ksplit
     ops.BWD_STATS, ops.WGRAD_SPLITS_R1, ops.USE_STEM_KERNEL = bwd_stats, splits_r1, stem
     model = mmvit4.MMVit4()
     model.load_state_dict(sd)
@@ -72,7 +72,7 @@ def main():
     r32 = oracle(case, torch.float32, sd)
     print("oracle fp32 vs fp64: pred gap %.3e" % (r32["__pred__"] - r64["__pred__"]).abs().max().item(), flush=True)
     variants = [("default", dict(serial=False, stream_k=False)),
-                ("ONE fma chain over all of K (rounds 1-2)", dict(serial=False, stream_k=False, ksplit=False)),
+                ("fp32-input MFMA chain in every GEMM (rounds 1-3)", dict(serial=False, stream_k=False, ksplit=False)),
                 ("one Encoder.forward per modality (twins)", dict(serial=False, stream_k=False, grouped=False)),
                 ("BatchNorm backward reductions as their own pass", dict(serial=False, stream_k=False, bwd_stats=False)),
                 ("round-1 weight-gradient splits", dict(serial=False, stream_k=False, splits_r1=True)),

@@ -47,10 +47,10 @@ def case(name, M, N, K, conv=None):
     for label, fn, sk, ks in (("3 launches, one stream", serial, False, True), ("same, ONE fma chain over K", serial, False, False),
                               ("3 launches, three streams", three_streams, False, True), ("one grouped launch (Z=3)", grouped, False, True),
                               ("grouped, ONE fma chain", grouped, False, False), ("grouped + stream-K", grouped, True, True)):
-        ops.STREAM_K, ops.K_SPLIT_ACCUM = sk, ks
+        ops.STREAM_K, ops.SPLIT_BF16 = sk, ks
         ms = timeit(fn)
         res.append("%s %.3f ms %.1f TF/s" % (label, ms, fl / ms / 1e9))
-    ops.STREAM_K, ops.K_SPLIT_ACCUM = False, True
+    ops.STREAM_K, ops.SPLIT_BF16 = False, True
     print("%-28s M=%6d N=%4d K=%4d | " % (name, M, N, K) + " | ".join(res), flush=True)
 
 

@@ -50,8 +50,8 @@ def family(name, mod):
 
 def main():
     B, D, HW, wseed = (int(v) for v in (sys.argv[1:5] + ["2", "3", "64", "11"][len(sys.argv) - 1:]))
-    ops.K_SPLIT_ACCUM = os.environ.get("CORRIF_KSPLIT", "0") == "1"       # two-level K accumulation of the forward / data-gradient GEMMs
-    print("ops.K_SPLIT_ACCUM =", ops.K_SPLIT_ACCUM)
+    ops.SPLIT_BF16 = os.environ.get("CORRIF_SPLIT_BF16", "1") == "1"      # 0 = the fp32-input MFMA chain in every GEMM
+    print("ops.SPLIT_BF16 =", ops.SPLIT_BF16)
     torch.manual_seed(0)
     ref = O.MMVit4()
     sd = helpers.make_state_dict(ref.state_dict(), seed=wseed, conv_gain=1.0)
