@@ -381,7 +381,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
         for (int e = 0; e < 4; ++e)
             if (col + e < p.N) bv[e] = bias[col + e];
     }
-    double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};      // fused norm statistics of this lane's 4 columns (double: no cancellation loss)
+    // fused norm statistics of this lane's 4 columns.  A lane sees at most 32 values per column: those are summed in fp32 (an error of a
+    // few ulp of values of the elements' own magnitude - no different from perturbing the inputs in their last bit, and unbiased), every
+    // sum ACROSS lanes / workgroups / the final reduction is in double (no cancellation loss in E[x^2] - E[x]^2).  The per-element
+    // cvt + add + fma in double cost 24 issue cycles against 8 in fp32: ~1000 cycles per tile and wave, 1/3 of the main loop at K = 64.
+    float fsum[4] = {0.f, 0.f, 0.f, 0.f}, fsq[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 bmu = {0.f, 0.f, 0.f, 0.f}, brs = {0.f, 0.f, 0.f, 0.f};      // backward-statistics mode: mean / rstd of this lane's 4 columns
     if (bs_x) {
 #pragma unroll
@@ -406,9 +410,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
             if (stats_part && !bs_x) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const double sv = (double)(p.stats_relu ? fmaxf(v[e], 0.f) : v[e]);
-                    ssum[e] += sv;
-                    ssq[e] += sv * sv;
+                    const float sv = p.stats_relu ? fmaxf(v[e], 0.f) : v[e];
+                    fsum[e] += sv;
+                    fsq[e] = fmaf(sv, sv, fsq[e]);
                 }
             }
             int64_t orow = row;
@@ -438,8 +442,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
                     for (int e = 0; e < 4; ++e) {
                         const float gm = yv[e] > 0.f ? v[e] : 0.f;
                         const float xh = (xv[e] - bmu[e]) * brs[e];
-                        ssum[e] += (double)gm;
-                        ssq[e] += (double)gm * (double)xh;
+                        fsum[e] += gm;
+                        fsq[e] = fmaf(gm, xh, fsq[e]);
                     }
                 }
                 *reinterpret_cast<f32x4*>(dst) = v;
@@ -455,8 +459,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
                     if (bs_x) {
                         const float yv = bs_y ? bs_y[(int64_t)row * p.bs_ldy + col + e] : 1.f;
                         const float gm = yv > 0.f ? x : 0.f;
-                        ssum[e] += (double)gm;
-                        ssq[e] += (double)gm * (double)((bs_x[(int64_t)row * p.bs_ldx + col + e] - bmu[e]) * brs[e]);
+                        fsum[e] += gm;
+                        fsq[e] = fmaf(gm, (bs_x[(int64_t)row * p.bs_ldx + col + e] - bmu[e]) * brs[e], fsq[e]);
                     }
                     dst[e] = x;
                 }
@@ -464,6 +468,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
         }
     }
     if (stats_part) {       // TM == 2: the wave's rows are one 64-row block; sum over the RPP lanes that share a column chunk
+        double ssum[4], ssq[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ssum[e] = (double)fsum[e]; ssq[e] = (double)fsq[e]; }
 #pragma unroll
         for (int off = CQ; off < 64; off <<= 1)
 #pragma unroll
@@ -1165,7 +1172,7 @@ static int pick_splits(int R, int M, int N, int BM, int BN, int Z) {
     if (maxs > 4096) maxs = 4096;
     // the split-bf16 kernels (BM >= 64) hold 46 KB of LDS: 3 workgroups per CU at ~120 TFLOP/s; the fp32-input ones 5 at ~85
     const bool split = BM >= 64;
-    const int64_t slots = (split ? 3 : 5) * 256;
+    const int64_t slots = (split ? (BM == 128 && BN == 128 ? 2 : 3) : 5) * 256;
     const double t_full = 2.0 * R * (double)M * N / (split ? 120e12 : 85e12), t_slab = 2.0 * (double)M * N * 4.0 / 3e12;
     int64_t best = 1;
     double best_t = 1e30;
@@ -1176,10 +1183,12 @@ static int pick_splits(int R, int M, int N, int BM, int BN, int Z) {
     }
     return (int)best;
 }
-static void wgrad_tile(int M, int N, int& BM, int& BN) {
+static void wgrad_tile(int M, int N, int& BM, int& BN, bool split = true) {
     BM = (M <= 32) ? 32 : 64;
     BN = (M <= 16 && !(M & 3)) ? 256 : 128;     // M <= 16: the 4x4x1 small-M kernel, 256-wide J tiles
     if (M >= 128 && N <= 64) { BM = 128; BN = 64; }      // N <= 64 (dV = P^T dO, 1x1 convs from 64 channels): a 128-wide J tile is half empty (50 -> 65 TF/s)
+    // split-bf16 loop: a 64 x 64 wave tile halves the staging (split) work and the LDS fragment reads per MFMA of the 32 x 64 one
+    if (split && M >= 128 && !(M & 127) && N >= 128) { BM = 128; BN = 128; }
 }
 
 extern "C" size_t corrif_wgrad_workspace(const CorrifWgrad* p) {
@@ -1226,7 +1235,7 @@ extern "C" int corrif_wgrad(const CorrifWgrad* p, void* stream) {
     a.g = make_devgeom(p->g, p->ldb);
     hipStream_t s = (hipStream_t)stream;
     int BM, BN;
-    wgrad_tile(p->M, p->N, BM, BN);
+    wgrad_tile(p->M, p->N, BM, BN, !p->f32_mfma);
     if (scalar) { BM = 64; BN = 128; }
     if (BN == 256) BM = 16;
     uint32_t tiles = (uint32_t)((p->M + BM - 1) / BM) * (uint32_t)((p->N + BN - 1) / BN);
@@ -1239,6 +1248,9 @@ extern "C" int corrif_wgrad(const CorrifWgrad* p, void* stream) {
     } else if (BN == 256) {
         int rc = launch_smallm_wgrad(a, (int)nz, s);
         if (rc != CORRIF_OK) return rc;
+    } else if (BM == 128 && BN == 128) {
+        if (a.g.is_gemm) hipLaunchKernelGGL((wgrad_split_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wgrad_split_kernel<128, 128, 2, 2, false>), grid, dim3(256), 0, s, a);
     } else if (BM == 128 && BN == 64) {
         if (!p->f32_mfma) {
             if (a.g.is_gemm) hipLaunchKernelGGL((wgrad_split_kernel<128, 64, 4, 1, true>), grid, dim3(256), 0, s, a);
