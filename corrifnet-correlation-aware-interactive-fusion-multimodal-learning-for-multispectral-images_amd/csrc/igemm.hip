@@ -9,6 +9,7 @@
 // lane (i, h) reads ONE float4 = k {4h..4h+3} of its row and feeds element j to MFMA j (4 MFMAs per
 // pair of ds_read_b128).  Activations are channels-last so a tap's channel run is contiguous: the
 // gather is done while staging global -> registers -> LDS, never as an im2col buffer.
+#include <type_traits>
 #include "common.h"
 #include "igemm_args.h"
 
@@ -48,11 +49,32 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define SPLIT_PB 80
-__device__ __forceinline__ void split3(const float x, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)x;
-    const float r1 = x - (float)h;          // exact
-    m = (__bf16)r1;
-    l = (__bf16)(r1 - (float)m);            // exact, and representable in 8 bits
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two values at a time: one v_cvt_pk_bf16_f32 per term and pair; h / m / l receive the packed bf16 pairs (x0's term in the low half)
+__device__ __forceinline__ void split3_pair(const float x0, const float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+    const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);      // exact
+    m = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+    const float s0 = r0 - __builtin_bit_cast(float, m << 16), s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);      // exact, <= 8 bits
+    l = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
+}
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// four values that are consecutive along k in one LDS row: three 8-byte stores (planes h, m, l)
+__device__ __forceinline__ void split3_store4(unsigned char* base, const int plane_bytes, const int off, const float v0, const float v1,
+                                              const float v2, const float v3) {
+    uint32_t h0, m0, l0, h1, m1, l1;
+    split3_pair(v0, v1, h0, m0, l0);
+    split3_pair(v2, v3, h1, m1, l1);
+    *reinterpret_cast<u32x2*>(base + off) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(base + plane_bytes + off) = u32x2{m0, m1};
+    *reinterpret_cast<u32x2*>(base + 2 * plane_bytes + off) = u32x2{l0, l1};
+}
+__device__ __forceinline__ void split3_store2(unsigned char* base, const int plane_bytes, const int off, const float v0, const float v1) {
+    uint32_t h, m, l;
+    split3_pair(v0, v1, h, m, l);
+    *reinterpret_cast<uint32_t*>(base + off) = h;
+    *reinterpret_cast<uint32_t*>(base + plane_bytes + off) = m;
+    *reinterpret_cast<uint32_t*>(base + 2 * plane_bytes + off) = l;
 }
 template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL, int SPLIT = 0>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, const float* __restrict__ A, const float* __restrict__ B, float* lds,
@@ -204,47 +226,39 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, const float* __
     auto store_tile = [&]() {
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         if constexpr (SPLIT) {
-            auto put4 = [&](unsigned char* base, int plane_bytes, int off, const f32x4 v) {      // 4 consecutive k of one row
-                bf16x4 h, m, l;
+            // zero fill (K / M / N edges, padding taps) costs one select per register: interior tiles - the common case - take a
+            // wave-uniform branch around all of them (56 of ~250 vector instructions per K tile; the loop is issue-bound)
+            auto stage = [&](auto masked) {
+                constexpr bool MK = decltype(masked)::value;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    __bf16 hh, mm, ll;
-                    split3(v[e], hh, mm, ll);
-                    h[e] = hh; m[e] = mm; l[e] = ll;
+                for (int i = 0; i < AI; ++i) {
+                    const f32x4 v = (!MK || ((okA >> i) & 1)) ? ra[i] : zero4;
+                    split3_store4(Ab, BM * SPLIT_PB, (ar + 32 * i) * SPLIT_PB + kc * 8, v[0], v[1], v[2], v[3]);
                 }
-                *reinterpret_cast<bf16x4*>(base + off) = h;
-                *reinterpret_cast<bf16x4*>(base + plane_bytes + off) = m;
-                *reinterpret_cast<bf16x4*>(base + 2 * plane_bytes + off) = l;
-            };
+                if constexpr (BL == 0) {
 #pragma unroll
-            for (int i = 0; i < AI; ++i) put4(Ab, BM * SPLIT_PB, (ar + 32 * i) * SPLIT_PB + kc * 8, (okA >> i) & 1 ? ra[i] : zero4);
-            if constexpr (BL == 0) {
+                    for (int i = 0; i < BI; ++i) {
+                        const f32x4 v = (!MK || ((okB >> i) & 1)) ? rb[i] : zero4;
+                        split3_store4(Bb, BN * SPLIT_PB, (ar + 32 * i) * SPLIT_PB + kc * 8, v[0], v[1], v[2], v[3]);
+                    }
+                } else {
+                    // [K][N] operand: this thread holds BI adjacent k rows x 4 columns; per column the BI values are one 2*BI-byte store
+                    constexpr int NG = BK / BI;
+                    const int nc = tid / NG, kgp = tid % NG;
+                    f32x4 v[BI];
 #pragma unroll
-                for (int i = 0; i < BI; ++i) put4(Bb, BN * SPLIT_PB, (ar + 32 * i) * SPLIT_PB + kc * 8, (okB >> i) & 1 ? rb[i] : zero4);
-            } else {
-                // [K][N] operand: this thread holds BI adjacent k rows x 4 columns; per column the BI values are one 2*BI-byte store
-                constexpr int NG = BK / BI;
-                const int nc = tid / NG, kgp = tid % NG;
-                f32x4 v[BI];
+                    for (int i = 0; i < BI; ++i) v[i] = (!MK || ((okB >> i) & 1)) ? rb[i] : zero4;
 #pragma unroll
-                for (int i = 0; i < BI; ++i) v[i] = (okB >> i) & 1 ? rb[i] : zero4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    __bf16 h[BI], m[BI], l[BI];
-#pragma unroll
-                    for (int i = 0; i < BI; ++i) split3(v[i][e], h[i], m[i], l[i]);
-                    const int off = (nc * 4 + e) * SPLIT_PB + kgp * BI * 2;
-                    if constexpr (BI == 4) {
-                        *reinterpret_cast<bf16x4*>(Bb + off) = bf16x4{h[0], h[1], h[2], h[3]};
-                        *reinterpret_cast<bf16x4*>(Bb + BN * SPLIT_PB + off) = bf16x4{m[0], m[1], m[2], m[3]};
-                        *reinterpret_cast<bf16x4*>(Bb + 2 * BN * SPLIT_PB + off) = bf16x4{l[0], l[1], l[2], l[3]};
-                    } else {
-                        *reinterpret_cast<bf16x2*>(Bb + off) = bf16x2{h[0], h[1]};
-                        *reinterpret_cast<bf16x2*>(Bb + BN * SPLIT_PB + off) = bf16x2{m[0], m[1]};
-                        *reinterpret_cast<bf16x2*>(Bb + 2 * BN * SPLIT_PB + off) = bf16x2{l[0], l[1]};
+                    for (int e = 0; e < 4; ++e) {
+                        const int off = (nc * 4 + e) * SPLIT_PB + kgp * BI * 2;
+                        if constexpr (BI == 4) split3_store4(Bb, BN * SPLIT_PB, off, v[0][e], v[1][e], v[2][e], v[3][e]);
+                        else split3_store2(Bb, BN * SPLIT_PB, off, v[0][e], v[1][e]);
                     }
                 }
-            }
+            };
+            constexpr uint32_t FA = (1u << AI) - 1, FB = (1u << BI) - 1;
+            if (__all((okA & FA) == FA && (okB & FB) == FB)) stage(std::false_type{});
+            else stage(std::true_type{});
             return;
         }
 #pragma unroll
@@ -301,18 +315,13 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, const float* __
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        f32x16 t = SPLIT == 2 ? sml[i][j] : acc[i][j];
+                        f32x16& t = SPLIT == 2 ? sml[i][j] : acc[i][j];
                         t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], t, 0, 0, 0);      // l h'
                         t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], t, 0, 0, 0);      // h l'
                         t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], t, 0, 0, 0);      // m m'
                         t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], t, 0, 0, 0);      // m h'
                         t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], t, 0, 0, 0);      // h m'
-                        if constexpr (SPLIT == 2) {
-                            sml[i][j] = t;
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);      // h h'
-                        } else {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], t, 0, 0, 0);
-                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);      // h h'
                     }
             }
         } else {
@@ -1042,45 +1051,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs p) {
             }
         }
     };
-    auto put = [&](unsigned char* base, const int plane_bytes, const int off, const float (&v)[4]) {
-        __bf16 h[4], m[4], l[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) split3(v[i], h[i], m[i], l[i]);
-        *reinterpret_cast<bf16x4*>(base + off) = bf16x4{h[0], h[1], h[2], h[3]};
-        *reinterpret_cast<bf16x4*>(base + plane_bytes + off) = bf16x4{m[0], m[1], m[2], m[3]};
-        *reinterpret_cast<bf16x4*>(base + 2 * plane_bytes + off) = bf16x4{l[0], l[1], l[2], l[3]};
-    };
-    auto put2 = [&](unsigned char* base, const int plane_bytes, const int off, const float (&v)[2]) {
-        __bf16 h[2], m[2], l[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) split3(v[i], h[i], m[i], l[i]);
-        *reinterpret_cast<bf16x2*>(base + off) = bf16x2{h[0], h[1]};
-        *reinterpret_cast<bf16x2*>(base + plane_bytes + off) = bf16x2{m[0], m[1]};
-        *reinterpret_cast<bf16x2*>(base + 2 * plane_bytes + off) = bf16x2{l[0], l[1]};
-    };
     auto store_tile = [&]() {
+        auto stage = [&](auto masked) {
+            constexpr bool MK = decltype(masked)::value;
+            auto va = [&](int i, int e) { return (!MK || ((okA >> i) & 1)) ? ra[i][e] : 0.f; };
+            auto vb = [&](int i, int e) { return (!MK || ((okB >> i) & 1)) ? rb[i][e] : 0.f; };
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int off = (ac * 4 + e) * SPLIT_PB + ag * AI * 2;
-            if constexpr (AI == 4) {
-                const float v[4] = {(okA & 1) ? ra[0][e] : 0.f, (okA & 2) ? ra[1][e] : 0.f, (okA & 4) ? ra[2][e] : 0.f, (okA & 8) ? ra[3][e] : 0.f};
-                put(Ab, BM * SPLIT_PB, off, v);
-            } else {
-                const float v[2] = {(okA & 1) ? ra[0][e] : 0.f, (okA & 2) ? ra[1][e] : 0.f};
-                put2(Ab, BM * SPLIT_PB, off, v);
+            for (int e = 0; e < 4; ++e) {
+                const int off = (ac * 4 + e) * SPLIT_PB + ag * AI * 2;
+                if constexpr (AI == 4) split3_store4(Ab, BM * SPLIT_PB, off, va(0, e), va(1, e), va(2, e), va(3, e));
+                else split3_store2(Ab, BM * SPLIT_PB, off, va(0, e), va(1, e));
             }
-        }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int off = (jc * 4 + e) * SPLIT_PB + bg * BI * 2;
-            if constexpr (BI == 4) {
-                const float v[4] = {(okB & 1) ? rb[0][e] : 0.f, (okB & 2) ? rb[1][e] : 0.f, (okB & 4) ? rb[2][e] : 0.f, (okB & 8) ? rb[3][e] : 0.f};
-                put(Bb, BN * SPLIT_PB, off, v);
-            } else {
-                const float v[2] = {(okB & 1) ? rb[0][e] : 0.f, (okB & 2) ? rb[1][e] : 0.f};
-                put2(Bb, BN * SPLIT_PB, off, v);
+            for (int e = 0; e < 4; ++e) {
+                const int off = (jc * 4 + e) * SPLIT_PB + bg * BI * 2;
+                if constexpr (BI == 4) split3_store4(Bb, BN * SPLIT_PB, off, vb(0, e), vb(1, e), vb(2, e), vb(3, e));
+                else split3_store2(Bb, BN * SPLIT_PB, off, vb(0, e), vb(1, e));
             }
-        }
+        };
+        constexpr uint32_t FA = (1u << AI) - 1, FB = (1u << BI) - 1;
+        if (__all(okA == FA && okB == FB)) stage(std::false_type{});      // interior tiles: no zero-fill selects (wave-uniform branch)
+        else stage(std::true_type{});
     };
 
     const int frow = lane & 31, fb = (lane >> 5) * 16;
@@ -1107,13 +1098,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int jj = 0; jj < TN; ++jj) {
-                        f32x16 t = sml[i][jj];
+                        f32x16& t = sml[i][jj];
                         t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[jj][0], t, 0, 0, 0);
                         t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[jj][2], t, 0, 0, 0);
                         t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[jj][1], t, 0, 0, 0);
                         t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[jj][0], t, 0, 0, 0);
                         t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[jj][1], t, 0, 0, 0);
-                        sml[i][jj] = t;
                         acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[jj][0], acc[i][jj], 0, 0, 0);
                     }
             }

@@ -113,7 +113,7 @@ __device__ __forceinline__ void split3(const f32x4 x, bf16x4& h, bf16x4& m, bf16
 
 // NACC: 1 = one fp32 accumulator per output element for all six products; 2 = hh' in one, the five small products in a second
 // (summed in the epilogue); PRODS: 6, or 3 (hh' + hm' + mh': "bf16x3", ~2^-17 per product - shown for contrast only)
-template <int MINW, int NACC, int PRODS>
+template <int MINW, int NACC, int PRODS, int ABL = 0>
 __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                float* __restrict__ C, int M, int N, int K) {
     constexpr int BM = 128, BN = 128, BKT = 32, AI = 4;
@@ -144,18 +144,19 @@ __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(const float* __re
             rb[i] = *reinterpret_cast<const f32x4*>(B + (int64_t)(n0 + ar + 32 * i) * K + kt * BKT + kc * 4);
         }
     };
-    unsigned char* const As = ldsb;                    // planes h, m, l of A, then of B
-    unsigned char* const Bs = ldsb + 3 * PLANE;
-    auto store_tile = [&]() {
+    constexpr int NBUF = ABL == 4 ? 2 : 1;
+    auto store_tile = [&](int buf) {
+        unsigned char* const As = ldsb + buf * 6 * PLANE;                    // planes h, m, l of A, then of B
+        unsigned char* const Bs = As + 3 * PLANE;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             bf16x4 h, m, l;
             const int off = (ar + 32 * i) * PB + kc * 8;
-            split3(ra[i], h, m, l);
+            if (ABL == 1) { for (int e = 0; e < 4; ++e) h[e] = (__bf16)ra[i][e]; m = h; l = h; } else split3(ra[i], h, m, l);
             *reinterpret_cast<bf16x4*>(As + off) = h;
             *reinterpret_cast<bf16x4*>(As + PLANE + off) = m;
             if (PRODS == 6) *reinterpret_cast<bf16x4*>(As + 2 * PLANE + off) = l;
-            split3(rb[i], h, m, l);
+            if (ABL == 1) { for (int e = 0; e < 4; ++e) h[e] = (__bf16)rb[i][e]; m = h; l = h; } else split3(rb[i], h, m, l);
             *reinterpret_cast<bf16x4*>(Bs + off) = h;
             *reinterpret_cast<bf16x4*>(Bs + PLANE + off) = m;
             if (PRODS == 6) *reinterpret_cast<bf16x4*>(Bs + 2 * PLANE + off) = l;
@@ -163,11 +164,9 @@ __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(const float* __re
     };
     const int frow = lane & 31, fk = (lane >> 5) * 16;       // byte offset of this lane's 8 bf16 inside a 16-deep k slab
     constexpr int NP = PRODS == 6 ? 3 : 2;
-    load_tile(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < nk) load_tile(kt + 1);
+    auto compute = [&](int buf) {
+        const unsigned char* const As = ldsb + buf * 6 * PLANE;
+        const unsigned char* const Bs = As + 3 * PLANE;
 #pragma unroll
         for (int kk = 0; kk < BKT / 16; ++kk) {
             bf16x8 a[2][NP], b[2][NP];
@@ -181,7 +180,6 @@ __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(const float* __re
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
                     b[j][p] = *reinterpret_cast<const bf16x8*>(Bs + p * PLANE + ((wn * 2 + j) * 32 + frow) * PB + kk * 32 + fk);
-            // small products first, the leading one last
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -197,7 +195,38 @@ __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(const float* __re
                     acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[0][i][j], 0, 0, 0);
                 }
         }
+    };
+    if constexpr (ABL == 3) {
+        bf16x8 a0, b0;
+        for (int e = 0; e < 8; ++e) { a0[e] = (__bf16)A[tid + e]; b0[e] = (__bf16)B[tid + e]; }
+        for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+            for (int s = 0; s < 12; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[(s & 1) * (NACC - 1)][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[(s & 1) * (NACC - 1)][i][j], 0, 0, 0);
+            asm volatile("" : "+v"(a0), "+v"(b0));
+        }
+    } else if constexpr (ABL == 4) {
+        load_tile(0);
+        store_tile(0);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_tile(kt + 1);
+            compute(kt & 1);
+            if (kt + 1 < nk) store_tile((kt + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        load_tile(0);
+        if (ABL == 2) { store_tile(0); __syncthreads(); }
+        for (int kt = 0; kt < nk; ++kt) {
+            if (ABL != 2) { store_tile(0); __syncthreads(); }
+            if (kt + 1 < nk) load_tile(kt + 1);
+            compute(0);
+            if (ABL != 2) __syncthreads();
+        }
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -210,6 +239,112 @@ __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(const float* __re
                 float v = acc[0][i][j][r];
                 if (NACC == 2) v += acc[1][i][j][r];
                 C[(int64_t)row * N + col] = v;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// P: K tiles of 16, LDS double-buffered, ONE barrier per tile, and the staging of tile k+1 (split + LDS stores) issued between the MFMA
+// groups of tile k by the same wave (an MFMA occupies the issue port for 8 of its 32 cycles; the split work rides in the other 24).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pair(const float x0, const float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+    const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    m = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+    const float s0 = r0 - __builtin_bit_cast(float, m << 16), s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+    l = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
+}
+template <int MINW, bool PIN>
+__global__ __launch_bounds__(256, MINW) void gemm_pipe_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                              int M, int N, int K) {
+    constexpr int BM = 128, BN = 128, BKT = 16;
+    constexpr int PB = 48;                             // 16 bf16 + 16 B pad: 12 dwords, 8 rows cover all 32 banks for the b128 reads
+    constexpr int PLANE = 128 * PB, BUF = 6 * PLANE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const uint32_t tiles_n = N / BN;
+    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int kc = tid & 3, ar = tid >> 2;             // chunk of 4 k, rows ar and ar + 64
+    f32x16 acc[2][2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
+    const int nk = K / BKT;
+    f32x4 g[2][4];                                     // [set][A0, A1, B0, B1]
+    auto load_tile = [&](int kt, f32x4 (&r)[4]) {
+        r[0] = *reinterpret_cast<const f32x4*>(A + (int64_t)(m0 + ar) * K + kt * BKT + kc * 4);
+        r[1] = *reinterpret_cast<const f32x4*>(A + (int64_t)(m0 + ar + 64) * K + kt * BKT + kc * 4);
+        r[2] = *reinterpret_cast<const f32x4*>(B + (int64_t)(n0 + ar) * K + kt * BKT + kc * 4);
+        r[3] = *reinterpret_cast<const f32x4*>(B + (int64_t)(n0 + ar + 64) * K + kt * BKT + kc * 4);
+    };
+    auto stage_chunk = [&](int buf, int c, const f32x4 v) {      // c: 0, 1 = A rows ar, ar + 64; 2, 3 = B
+        unsigned char* base = ldsb + buf * BUF + (c >> 1) * 3 * PLANE + (ar + 64 * (c & 1)) * PB + kc * 8;
+        uint32_t h0, m0_, l0, h1, m1, l1;
+        split3_pair(v[0], v[1], h0, m0_, l0);
+        split3_pair(v[2], v[3], h1, m1, l1);
+        *reinterpret_cast<u32x2*>(base) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(base + PLANE) = u32x2{m0_, m1};
+        *reinterpret_cast<u32x2*>(base + 2 * PLANE) = u32x2{l0, l1};
+    };
+    const int frow = lane & 31, fk = (lane >> 5) * 16;
+    auto step = [&](int kt, f32x4 (&cur)[4], f32x4 (&nxt)[4]) {
+        // cur: registers of tile kt + 1 (loaded one iteration ago), nxt: receives tile kt + 2
+        const int buf = kt & 1;
+        if (kt + 2 < nk) load_tile(kt + 2, nxt);
+        const unsigned char* As = ldsb + buf * BUF;
+        const unsigned char* Bs = As + 3 * PLANE;
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const bf16x8*>(As + p * PLANE + ((wm * 2 + i) * 32 + frow) * PB + fk);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[j][p] = *reinterpret_cast<const bf16x8*>(Bs + p * PLANE + ((wn * 2 + j) * 32 + frow) * PB + fk);
+#pragma unroll
+        for (int ij = 0; ij < 4; ++ij) {
+            const int i = ij >> 1, j = ij & 1;
+            if (kt + 1 < nk) stage_chunk(buf ^ 1, ij, cur[ij]);
+            if (PIN) __builtin_amdgcn_sched_barrier(0);
+            f32x16& s = acc[1][i][j];
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], s, 0, 0, 0);
+            acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[0][i][j], 0, 0, 0);
+            if (PIN) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+    load_tile(0, g[0]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) stage_chunk(0, c, g[0][c]);
+    if (nk > 1) load_tile(1, g[1]);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {               // nk even (K multiple of 32)
+        step(kt, g[1], g[0]);
+        step(kt + 1, g[0], g[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + (wn * 2 + j) * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                C[(int64_t)row * N + col] = acc[0][i][j][r] + acc[1][i][j][r];
             }
     }
 }
@@ -308,6 +443,12 @@ int main() {
         RUN("S6   six bf16 products, one accumulator, (256,3)", (gemm_split_kernel<3, 1, 6>), 6 * 128 * 80);
         RUN("S6x2 six bf16 products, hh' apart from the small five", (gemm_split_kernel<2, 2, 6>), 6 * 128 * 80);
         RUN("S3   three bf16 products (contrast: not fp32-grade)", (gemm_split_kernel<2, 1, 3>), 6 * 128 * 80);
+        RUN("S6x2 ablation: convert only, no split arithmetic", (gemm_split_kernel<2, 2, 6, 1>), 6 * 128 * 80);
+        RUN("S6x2 ablation: no LDS stores / barriers in the loop", (gemm_split_kernel<2, 2, 6, 2>), 6 * 128 * 80);
+        RUN("S6x2 ablation: MFMA only", (gemm_split_kernel<2, 2, 6, 3>), 6 * 128 * 80);
+        RUN("S6x2 double-buffered LDS, one barrier per tile (1 WG/CU)", (gemm_split_kernel<1, 2, 6, 4>), 2 * 6 * 128 * 80);
+        RUN("P    K tiles of 16, double-buffered, staging between MFMA groups (pinned)", (gemm_pipe_kernel<2, true>), 2 * 6 * 128 * 48);
+        RUN("P    same, compiler's own order", (gemm_pipe_kernel<2, false>), 2 * 6 * 128 * 48);
         CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(Ref)); CK(hipFree(err));
     }
     return 0;
