@@ -31,6 +31,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA (MI355X_MICROARCH.md): the instruction peak of the split-bf16 main loops
 FLOP_PER_IMAGE_FWD_BWD = 645.9e9          # 215.3 GFLOP forward x 3 at D=4, 224^2
 
 
@@ -50,10 +51,12 @@ class MfmaTimer:
         if not self.on:
             return fn(*a, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.ops.LAST_SPLIT = 0
         e0.record()
         r = fn(*a, **kw)
         e1.record()
-        self.rec.append((flops, e0, e1, key))
+        # split: the launch ran the split-bf16 main loop (six bf16 MFMAs per fp32 product) - only gemm / wgrad launches can
+        self.rec.append((flops, e0, e1, key, bool(self.ops.LAST_SPLIT) and key[0] in ("gemm", "conv", "dgrad", "wgrad")))
         return r
 
     def gemm(self, *a, **kw):       # (A, lda, B, ldb, b_layout, C, ldc, M, N, K, Cs, geom, ...)
@@ -93,7 +96,7 @@ class MfmaTimer:
 
     def by_shape(self):
         agg = {}
-        for fl, e0, e1, key in self.rec:
+        for fl, e0, e1, key, _sp in self.rec:
             d = agg.setdefault(key, [0, 0.0, 0.0])
             d[0] += 1
             d[1] += e0.elapsed_time(e1)
@@ -119,7 +122,7 @@ class MfmaTimer:
     def by_kind(self, overhead_ms=0.0, steps=1):
         """per kernel family: ms per step and achieved TFLOP/s (conv / dgrad / gemm = gemm_fwd_kernel in its three roles)"""
         agg = {}
-        for fl, e0, e1, key in self.rec:
+        for fl, e0, e1, key, _sp in self.rec:
             d = agg.setdefault(key[0], [0.0, 0.0, 0])
             d[0] += max(e0.elapsed_time(e1) - overhead_ms, 0.0)
             d[1] += fl
@@ -131,6 +134,18 @@ class MfmaTimer:
         fl = sum(r[0] for r in self.rec)
         ms = sum(max(r[1].elapsed_time(r[2]) - overhead_ms, 0.0) for r in self.rec)
         return fl, ms, len(self.rec)
+
+    def executed(self, overhead_ms=0.0):
+        """The matrix-core work as ISSUED: a split launch executes 6 bf16 MFMA products per fp32 product (dense bf16 peak 2500 TFLOP/s), the
+        others v_mfma_f32_* (157.3).  Returns (fp32-equivalent flops of split launches, their ms, flops of fp32-input launches, their ms)."""
+        fs = ms_s = ff = ms_f = 0.0
+        for fl, e0, e1, key, sp in self.rec:
+            t = max(e0.elapsed_time(e1) - overhead_ms, 0.0)
+            if sp:
+                fs += fl; ms_s += t
+            else:
+                ff += fl; ms_f += t
+        return fs, ms_s, ff, ms_f
 
 
 class HbmTimer:
@@ -412,9 +427,9 @@ def main():
         for _ in range(kt_steps):
             for _ in range(80):
                 timer._gemm(ga.data_ptr(), 4096, gb.data_ptr(), 4096, 1, gc.data_ptr(), 4096, 4096, 4096, 4096, 4096, gg)
-            timer.on = hbm.on = True
+            timer.on = hbm.on = ops.TRACK_SPLIT = True
             step()
-            timer.on = hbm.on = False
+            timer.on = hbm.on = ops.TRACK_SPLIT = False
         torch.cuda.synchronize()
         del ga, gb, gc
         model.concurrent_branches = True
@@ -476,6 +491,10 @@ def main():
             algo = FLOP_PER_IMAGE_FWD_BWD * B if std else None
             launched = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             ach = launched
+            fs, ms_s, ff, ms_f = timer.executed(ovh)
+            # fraction of the INSTRUCTION peaks: the time the issued MFMA work would need at its own dense peak (6 bf16 products per fp32
+            # product of a split launch at 2500 TFLOP/s; fp32-input MFMA at 157.3) over the time the family took
+            t_roof_ms = (6.0 * fs / (PEAK_BF16_MFMA_TFLOPS * 1e12) + ff / (PEAK_FP32_MFMA_TFLOPS * 1e12)) * 1e3
             algo_ach = (algo / (per_step_ms * 1e-3) / 1e12) if (algo and per_step_ms > 0) else None
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
@@ -483,7 +502,18 @@ def main():
                                "algorithmic_frac": round(algo_ach / PEAK_FP32_MFMA_TFLOPS, 4) if algo_ach else None,
                                "traffic_note": "HBM bytes per step of the same launches (sum over the MFMA family), rocprofv3 FETCH_SIZE x2 + "
                                                "WRITE_SIZE from separate --pmc passes (profiles/%s); algorithmic = 243 GB" % traffic_src,
-                               "kernel": "gemm_fwd_kernel+wgrad_kernel+conv3_patch_kernel+stem_*+flash_* (fp32 MFMA implicit GEMM / patch conv / attention)",
+                               "kernel": "gemm_fwd_kernel+wgrad_split_kernel (split-bf16 main loops) + conv3_patch_kernel+stem_*+flash_* (fp32-input MFMA)",
+                               "issued": {"note": "gemm_fwd / wgrad launches on 128-row tiles form every fp32 product from six bf16 MFMA products of exactly "
+                                                  "split operands (fp32-grade result, DESIGN section 4); achieved / peak above stay in fp32-equivalent "
+                                                  "flops against the fp32-input MFMA peak; this block prices the work as issued",
+                                          "split_bf16x6": {"fp32_equiv_tflops": round(fs / (ms_s * 1e-3) / 1e12, 1) if ms_s > 0 else None,
+                                                           "bf16_tflops_issued": round(6 * fs / (ms_s * 1e-3) / 1e12, 1) if ms_s > 0 else None,
+                                                           "peak_bf16": PEAK_BF16_MFMA_TFLOPS, "ms_per_step": round(ms_s / max(kt_steps, 1), 2),
+                                                           "frac_of_bf16_peak": round(6 * fs / (ms_s * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if ms_s > 0 else None},
+                                          "fp32_input_mfma": {"tflops": round(ff / (ms_f * 1e-3) / 1e12, 1) if ms_f > 0 else None,
+                                                              "ms_per_step": round(ms_f / max(kt_steps, 1), 2),
+                                                              "frac_of_fp32_peak": round(ff / (ms_f * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if ms_f > 0 else None},
+                                          "frac_of_instruction_peaks": round(t_roof_ms / ms, 4) if ms > 0 else None},
                                "launches_per_step": n // max(kt_steps, 1), "mfma_ms_per_step": round(per_step_ms, 3),
                                "algorithmic_gflop_per_step": round(algo / 1e9, 1) if algo else None,
                                "launched_gflop_per_step": round(fl / max(kt_steps, 1) / 1e9, 1),

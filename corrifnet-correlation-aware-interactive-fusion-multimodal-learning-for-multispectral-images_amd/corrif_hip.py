@@ -64,6 +64,8 @@ _SIGS = {
     "corrif_build_arch": (C.c_char_p, []),
     "corrif_gemm_fwd": (i32, [C.POINTER(Gemm), ptr]),
     "corrif_gemm_fwd_workspace": (C.c_size_t, [C.POINTER(Gemm)]),
+    "corrif_gemm_fwd_is_split": (i32, [C.POINTER(Gemm)]),
+    "corrif_wgrad_is_split": (i32, [C.POINTER(Wgrad)]),
     "corrif_wgrad": (i32, [C.POINTER(Wgrad), ptr]),
     "corrif_wgrad_workspace": (C.c_size_t, [C.POINTER(Wgrad)]),
     "corrif_wgrad_plan": (i32, [i32, i32, i32, i32]),

@@ -81,7 +81,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, const float* __
                                               const int m0, const int n0, const int kt0, const int kt1,
                                               f32x16 (&acc)[BM / WM / 32][BN / WN / 32]) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    static_assert(!SPLIT || (VEC == 4 && BM == 128 && (BN == 128 || BN == 64)), "split-bf16 main loop: 128-row tiles of the float4 loader");
+    static_assert(!SPLIT || (VEC == 4 && (BM == 128 || BM == 64) && (BN == 128 || BN == 64)), "split-bf16 main loop: float4 loader, 64- / 128-wide tiles");
     constexpr int AI = BM / 32, BI = BN / 32;      // float4 chunks per thread per K tile
     constexpr int PBT = BN + 4;                           // row pitch of the K-major B tile (BL == 1)
     float* const As = lds;
@@ -390,11 +390,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
         for (int e = 0; e < 4; ++e)
             if (col + e < p.N) bv[e] = bias[col + e];
     }
-    // fused norm statistics of this lane's 4 columns.  A lane sees at most 32 values per column: those are summed in fp32 (an error of a
-    // few ulp of values of the elements' own magnitude - no different from perturbing the inputs in their last bit, and unbiased), every
-    // sum ACROSS lanes / workgroups / the final reduction is in double (no cancellation loss in E[x^2] - E[x]^2).  The per-element
-    // cvt + add + fma in double cost 24 issue cycles against 8 in fp32: ~1000 cycles per tile and wave, 1/3 of the main loop at K = 64.
-    float fsum[4] = {0.f, 0.f, 0.f, 0.f}, fsq[4] = {0.f, 0.f, 0.f, 0.f};
+    // fused norm statistics of this lane's 4 columns, in double from the first add on: E[x^2] - E[x]^2 cancels in nearly constant
+    // channels, and the reference (ATen on the CPU) accumulates its batch statistics in double too.  (fp32 per-lane partials of <= 32
+    // values were tried in round 3: -1 ms per step, but a channel with var / mean^2 ~ 1e-5 then carries a 1 % error in rstd - the MMVit2
+    // 32 x 32 fixture lost a gradient-norm bracket to it.)
+    double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};
     f32x4 bmu = {0.f, 0.f, 0.f, 0.f}, brs = {0.f, 0.f, 0.f, 0.f};      // backward-statistics mode: mean / rstd of this lane's 4 columns
     if (bs_x) {
 #pragma unroll
@@ -419,9 +419,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
             if (stats_part && !bs_x) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float sv = p.stats_relu ? fmaxf(v[e], 0.f) : v[e];
-                    fsum[e] += sv;
-                    fsq[e] = fmaf(sv, sv, fsq[e]);
+                    const double sv = (double)(p.stats_relu ? fmaxf(v[e], 0.f) : v[e]);
+                    ssum[e] += sv;
+                    ssq[e] += sv * sv;
                 }
             }
             int64_t orow = row;
@@ -451,8 +451,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
                     for (int e = 0; e < 4; ++e) {
                         const float gm = yv[e] > 0.f ? v[e] : 0.f;
                         const float xh = (xv[e] - bmu[e]) * brs[e];
-                        fsum[e] += gm;
-                        fsq[e] = fmaf(gm, xh, fsq[e]);
+                        ssum[e] += (double)gm;
+                        ssq[e] += (double)gm * (double)xh;
                     }
                 }
                 *reinterpret_cast<f32x4*>(dst) = v;
@@ -468,8 +468,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
                     if (bs_x) {
                         const float yv = bs_y ? bs_y[(int64_t)row * p.bs_ldy + col + e] : 1.f;
                         const float gm = yv > 0.f ? x : 0.f;
-                        fsum[e] += gm;
-                        fsq[e] = fmaf(gm, (bs_x[(int64_t)row * p.bs_ldx + col + e] - bmu[e]) * brs[e], fsq[e]);
+                        ssum[e] += (double)gm;
+                        ssq[e] += (double)gm * (double)((bs_x[(int64_t)row * p.bs_ldx + col + e] - bmu[e]) * brs[e]);
                     }
                     dst[e] = x;
                 }
@@ -477,9 +477,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
         }
     }
     if (stats_part) {       // TM == 2: the wave's rows are one 64-row block; sum over the RPP lanes that share a column chunk
-        double ssum[4], ssq[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { ssum[e] = (double)fsum[e]; ssq[e] = (double)fsq[e]; }
 #pragma unroll
         for (int off = CQ; off < 64; off <<= 1)
 #pragma unroll
@@ -659,13 +656,18 @@ static int sk_plan(int64_t tiles_total, int nk, int slots) {
     return (int)G;
 }
 
+static thread_local int g_plan_split = 0;      // set by the plan / launch: did the chosen tile run the split-bf16 main loop (corrif_gemm_fwd_is_split)
 template <int BM, int BN, int WM, int WN, int VEC, bool GEMM, int BL>
 static int launch_variant(GemmArgs& a, int Z, hipStream_t s, bool plan_only, size_t* ws_bytes) {
-    // stream-K and the split-bf16 main loop exist for the two tiles that carry the encoder's shapes (128x128, 128x64, float4 loader)
+    // stream-K exists for the two tiles that carry the encoder's shapes (128x128, 128x64, float4 loader); the split-bf16 main loop for
+    // those and the 64x64 tile - every tile the N > 32 tile choice can land on, which depends on the launch's tile count and therefore on
+    // Z: a grouped launch (Z = 3) and its three per-modality twins must run the same arithmetic to stay bit-identical
     constexpr bool BIG = VEC == 4 && BM == 128 && (BN == 128 || BN == 64);
+    constexpr bool SPL = VEC == 4 && (BM == 128 || BM == 64) && (BN == 128 || BN == 64);
     const int64_t tiles_mn = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int nk = (a.K + BK - 1) / BK;
-    const bool split = BIG && !a.f32_mfma;
+    const bool split = SPL && !a.f32_mfma;
+    g_plan_split = split ? 1 : 0;
     int G = 0;
     if constexpr (BIG) {
         static int per_cu[2] = {0, 0};
@@ -678,7 +680,7 @@ static int launch_variant(GemmArgs& a, int Z, hipStream_t s, bool plan_only, siz
     if (G && !a.sk_ws) return CORRIF_EINVAL;                  // the caller did not provide the workspace corrif_gemm_fwd_workspace asked for
     if (!G) {
         dim3 grid((uint32_t)tiles_mn, 1, Z);
-        if constexpr (BIG) {
+        if constexpr (SPL) {
             if (split) {
                 hipLaunchKernelGGL((gemm_fwd_kernel<BM, BN, WM, WN, VEC, GEMM, BL, 2>), grid, dim3(256), 0, s, a);
                 CORRIF_CHECK_LAUNCH();
@@ -797,6 +799,13 @@ static int gemm_fwd_impl(const CorrifGemm* p, void* stream, bool plan_only, size
 }
 
 extern "C" int corrif_gemm_fwd(const CorrifGemm* p, void* stream) { return gemm_fwd_impl(p, stream, false, nullptr); }
+
+extern "C" int corrif_gemm_fwd_is_split(const CorrifGemm* p) {
+    size_t n = 0;
+    g_plan_split = 0;
+    if (gemm_fwd_impl(p, nullptr, true, &n) != CORRIF_OK) return 0;
+    return g_plan_split;
+}
 
 extern "C" size_t corrif_gemm_fwd_workspace(const CorrifGemm* p) {
     size_t n = 0;
@@ -1190,6 +1199,13 @@ extern "C" int corrif_wgrad_plan(int32_t R, int32_t M, int32_t N, int32_t Z) {
     wgrad_tile(M, N, BM, BN);
     if (BN == 256) BM = 16;
     return pick_splits(R, M, N, BM, BN, Z);
+}
+
+extern "C" int corrif_wgrad_is_split(const CorrifWgrad* p) {
+    if (!p || p->f32_mfma || p->Cs == 1) return 0;
+    int BM, BN;
+    wgrad_tile(p->M, p->N, BM, BN, true);
+    return BN != 256 && BM >= 64;
 }
 
 extern "C" int corrif_slab_reduce(const float* ws, float* out, int64_t n, int32_t count, void* stream) {

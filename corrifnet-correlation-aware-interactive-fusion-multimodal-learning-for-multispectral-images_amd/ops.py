@@ -104,6 +104,8 @@ STREAM_K_GROUPED = False
 # result is MORE accurate than the fp32-input MFMA chain it replaces (one rounding per 16 products of the K sum instead of 16: 0.36x the
 # error at K = 2304-4608, tools/split_lab.hip) and 1.4-1.5x faster.  False = v_mfma_f32_32x32x2_f32 everywhere (rounds 1-3; A/B).
 SPLIT_BF16 = True
+TRACK_SPLIT = False       # measurement (bench.py): LAST_SPLIT = did the last gemm / wgrad launch take the split-bf16 loop (corrif_*_is_split)
+LAST_SPLIT = 0
 
 
 def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, addend=None, ld_add=0, act=ACT_NONE,
@@ -141,6 +143,9 @@ def gemm(A, lda, Bm, ldb, b_layout, Cout, ldc, M, N, K, Cs, geom, bias=None, add
     sk = STREAM_K or (STREAM_K_LONG and K >= 2048 and Z == 1 and M * N <= 128 * 128 * 512) or (STREAM_K_GROUPED and zs is not None and K >= 2048)
     g.no_split = 0 if sk else 1
     g.f32_mfma = 0 if SPLIT_BF16 else 1
+    if TRACK_SPLIT:
+        global LAST_SPLIT
+        LAST_SPLIT = lib().corrif_gemm_fwd_is_split(g)
     if sk:
         nws = lib().corrif_gemm_fwd_workspace(g)      # stream-K split: slabs for the tiles a share boundary cuts
         if nws:
@@ -175,6 +180,9 @@ def wgrad(A, lda, Bm, ldb, Cs, Cout, ldc, R, M, N, geom, dev, Z=1, Zi=1, sA=(0, 
     w.sC_o, w.sC_i = sC
     w.g = geom
     w.f32_mfma = 0 if SPLIT_BF16 else 1
+    if TRACK_SPLIT:
+        global LAST_SPLIT
+        LAST_SPLIT = lib().corrif_wgrad_is_split(w)
     if Z > 1:                   # grouped weight gradient (Zi = 1): row splits per group; batched attention products (Zi > 1): none
         w.splits = lib().corrif_wgrad_plan(R, M, N, Z) if Zi == 1 else 1
     else:

@@ -125,6 +125,7 @@ typedef struct CorrifGemm {
     int32_t f32_mfma;
 } CorrifGemm;
 int corrif_gemm_fwd(const CorrifGemm* p, void* stream);
+int corrif_gemm_fwd_is_split(const CorrifGemm* p);      /* 1 = this launch takes the split-bf16 main loop (six bf16 MFMAs per fp32 product), 0 = v_mfma_f32_* */
 size_t corrif_gemm_fwd_workspace(const CorrifGemm* p);   /* bytes of CorrifGemm.ws this launch needs; queries the device's CU count */
 
 /* The encoder stem (mmvit4.py:120,172: Conv3d(1, 64, (3,7,7), stride (1,2,2), padding (1,3,3), bias=False) = inflate_conv of the
@@ -155,6 +156,7 @@ typedef struct CorrifWgrad {
     int32_t f32_mfma;                             /* ABI 7: 1 = the fp32-input MFMA loop instead of the split-bf16 one (see CorrifGemm.f32_mfma) */
 } CorrifWgrad;
 int corrif_wgrad(const CorrifWgrad* p, void* stream);
+int corrif_wgrad_is_split(const CorrifWgrad* p);       /* same question for a weight-gradient launch */
 size_t corrif_wgrad_workspace(const CorrifWgrad* p);   /* bytes; host-only */
 int corrif_wgrad_plan(int32_t R, int32_t M, int32_t N, int32_t Z);  /* recommended `splits` for a launch of Z batches; host-only */
 

@@ -12,7 +12,7 @@ def bench(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-for (M, N, K) in [(4096, 4096, 4096), (25088, 256, 2304), (6272, 512, 4608), (100352, 128, 1152), (25088, 1024, 256)]:
+for (M, N, K) in [(4096, 4096, 4096), (25088, 256, 2304), (6272, 512, 4608), (100352, 128, 1152), (25088, 1024, 256), (401408, 256, 64), (100352, 512, 128)]:
     A = torch.randn(M, K, device=dev); B = torch.randn(N, K, device=dev); C = torch.empty(M, N, device=dev)
     fl = 2.0 * M * N * K
     ms = bench(lambda: ops.gemm(A.data_ptr(), K, B.data_ptr(), K, 0, C.data_ptr(), N, M, N, K, K, H.gemm_geom()))

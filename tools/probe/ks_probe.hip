@@ -8,4 +8,5 @@ template __global__ void gemm_fwd_kernel<128, 64, 2, 2, 4, false, 0, 2>(GemmArgs
 template __global__ void gemm_fwd_kernel<128, 64, 2, 2, 4, true, 1, 2>(GemmArgs);
 template __global__ void gemm_sk_kernel<128, 128, 2, 2, 4, false, 0, 1>(GemmArgs);
 template __global__ void wgrad_split_kernel<64, 128, 2, 2, false>(WgradArgs);
-template __global__ void wgrad_split_kernel<128, 128, 2, 2, false>(WgradArgs);
+template __global__ void gemm_fwd_kernel<64, 64, 2, 2, 4, false, 0, 2>(GemmArgs);
+template __global__ void gemm_fwd_kernel<64, 64, 2, 2, 4, true, 1, 2>(GemmArgs);

@@ -358,7 +358,7 @@ __global__ void fill_kernel(float* p, int64_t n, uint32_t seed, float scale) {
         y ^= y >> 17;
         const float u = ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f) - 0.5f;         // (-0.5, 0.5), 24 bits
         const float v = 0.25f + (float)(y >> 8) * (1.0f / 16777216.0f);                  // [0.25, 1.25)
-        p[i] = u * v * v * v * scale;
+        p[i] = scale < 0.f ? fabsf(u) * v * v * v * -scale : u * v * v * v * scale;
     }
 }
 
@@ -373,20 +373,22 @@ __global__ void ref_kernel(const float* __restrict__ A, const float* __restrict_
 }
 __global__ void err_kernel(const float* __restrict__ C, const double* __restrict__ Ref, double* __restrict__ out, int R, int N) {
     // one block: sum (c - ref)^2 and sum ref^2
-    __shared__ double s1[256], s2[256];
-    double a = 0, b = 0;
+    __shared__ double s1[256], s2[256], s3[256], s4[256];
+    double a = 0, b = 0, c = 0, e = 0;
     for (int64_t i = threadIdx.x; i < (int64_t)R * N; i += 256) {
         const double d = (double)C[i] - Ref[i];
         a += d * d;
         b += Ref[i] * Ref[i];
+        c += d;                      // signed: a systematic bias of the accumulation shows here
+        e += fabs(Ref[i]);
     }
-    s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+    s1[threadIdx.x] = a; s2[threadIdx.x] = b; s3[threadIdx.x] = c; s4[threadIdx.x] = e;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) { s1[threadIdx.x] += s1[threadIdx.x + s]; s2[threadIdx.x] += s2[threadIdx.x + s]; }
+        if ((int)threadIdx.x < s) { s1[threadIdx.x] += s1[threadIdx.x + s]; s2[threadIdx.x] += s2[threadIdx.x + s]; s3[threadIdx.x] += s3[threadIdx.x + s]; s4[threadIdx.x] += s4[threadIdx.x + s]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out[0] = s1[0]; out[1] = s2[0]; }
+    if (threadIdx.x == 0) { out[0] = s1[0]; out[1] = s2[0]; out[2] = s3[0]; out[3] = s4[0]; }
 }
 
 struct Shape { int M, N, K; };
@@ -408,26 +410,30 @@ static float time_it(F f, int reps) {
 }
 
 int main() {
-    Shape shapes[] = {{4096, 4096, 4096}, {25088, 256, 2304}, {6272, 512, 4608}, {100352, 128, 1152}, {25088, 1024, 256}, {401408, 256, 64}};
+    Shape shapes[] = {{4096, 4096, 4096}, {25088, 256, 2304}, {6272, 512, 4608}, {100352, 128, 1152}, {25088, 1024, 256}, {401408, 256, 64},
+                      {-4096, 256, 2304}, {-4096, 256, 256}};      // M < 0: all-positive operands (every product has the same sign: accumulation bias shows)
     const int R = 256;
-    for (auto& sh : shapes) {
+    for (auto& sh0 : shapes) {
+        Shape sh = sh0;
+        const bool positive = sh.M < 0;
+        if (positive) sh.M = -sh.M;
         const int M = sh.M, N = sh.N, K = sh.K;
         float *A, *B, *C;
         double *Ref, *err;
         CK(hipMalloc(&A, (size_t)M * K * 4)); CK(hipMalloc(&B, (size_t)N * K * 4)); CK(hipMalloc(&C, (size_t)M * N * 4));
-        CK(hipMalloc(&Ref, (size_t)R * N * 8)); CK(hipMalloc(&err, 16));
-        fill_kernel<<<2048, 256>>>(A, (int64_t)M * K, 1u, 4.0f);
-        fill_kernel<<<2048, 256>>>(B, (int64_t)N * K, 7u, 0.25f);
+        CK(hipMalloc(&Ref, (size_t)R * N * 8)); CK(hipMalloc(&err, 32));
+        fill_kernel<<<2048, 256>>>(A, (int64_t)M * K, 1u, positive ? -4.0f : 4.0f);
+        fill_kernel<<<2048, 256>>>(B, (int64_t)N * K, 7u, positive ? -0.25f : 0.25f);
         ref_kernel<<<(unsigned)(((int64_t)R * N + 255) / 256), 256>>>(A, B, Ref, R, N, K);
         CK(hipDeviceSynchronize());
         const unsigned tiles = (unsigned)(M / 128) * (N / 128);
         const double fl = 2.0 * M * N * K;
-        printf("shape M %d N %d K %d  tiles %u\n", M, N, K, tiles);
+        printf("shape M %d N %d K %d  tiles %u%s\n", M, N, K, tiles, positive ? "  (all-positive operands)" : "");
         auto report = [&](const char* name, float ms) {
-            double h[2];
+            double h[4];
             err_kernel<<<1, 256>>>(C, Ref, err, R, N);
-            CK(hipMemcpy(h, err, 16, hipMemcpyDeviceToHost));
-            printf("  %-58s %8.3f ms  %6.1f TF/s (fp32-equivalent)   rel L2 error vs fp64 %.3e\n", name, ms, fl / ms / 1e9, sqrt(h[0] / h[1]));
+            CK(hipMemcpy(h, err, 32, hipMemcpyDeviceToHost));
+            printf("  %-58s %8.3f ms  %6.1f TF/s (fp32-equivalent)   rel L2 error vs fp64 %.3e   signed mean error / mean |ref| %+.3e\n", name, ms, fl / ms / 1e9, sqrt(h[0] / h[1]), h[2] / h[3]);
             fflush(stdout);
         };
 #define RUN(NAME, KERNEL, LDSB)                                                                          \

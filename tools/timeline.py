@@ -17,7 +17,7 @@ else:
 ev = [e for e in ev if e[0] < t_end]
 print("window: %.1f ms" % (span / 1e6))
 ev = [e for e in ev if e[1] > t0]
-def is_mfma(n): return any(k in n for k in ("gemm_fwd_kernel", "gemm_sk_kernel", "gemm_sk_fixup", "wgrad_kernel", "conv3_patch", "smalln_fwd", "smallm_wgrad", "conv1x1_small", "flash_fwd", "flash_bwd", "stem_fwd", "stem_wgrad"))
+def is_mfma(n): return any(k in n for k in ("gemm_fwd_kernel", "gemm_sk_kernel", "gemm_sk_fixup", "wgrad_kernel", "wgrad_split_kernel", "conv3_patch", "smalln_fwd", "smallm_wgrad", "conv1x1_small", "flash_fwd", "flash_bwd", "stem_fwd", "stem_wgrad"))
 pts = []
 for s, e, n, q in ev:
     s = max(s, t0)
