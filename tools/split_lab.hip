@@ -113,12 +113,15 @@ __device__ __forceinline__ void split3(const f32x4 x, bf16x4& h, bf16x4& m, bf16
 
 // NACC: 1 = one fp32 accumulator per output element for all six products; 2 = hh' in one, the five small products in a second
 // (summed in the epilogue); PRODS: 6, or 3 (hh' + hm' + mh': "bf16x3", ~2^-17 per product - shown for contrast only)
-template <int MINW, int NACC, int PRODS, int ABL = 0>
+// PBV: bytes per LDS row of one plane (planes apart), or, negative, bytes per row with the three planes of a row side by side
+template <int MINW, int NACC, int PRODS, int ABL = 0, int PBV = 80>
 __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                float* __restrict__ C, int M, int N, int K) {
     constexpr int BM = 128, BN = 128, BKT = 32, AI = 4;
-    constexpr int PB = 80;                             // bytes per LDS row of one plane: 32 bf16 + 16 B pad (20 dwords: 8 rows cover all 32 banks)
-    constexpr int PLANE = BM * PB;                     // one plane of one operand
+    constexpr bool SWZ = PBV == 64;                    // 64-byte rows (no padding), 16-byte chunk index XOR ((row >> 1) + (row >> 3)) & 3
+    constexpr int PB = PBV > 0 ? PBV : -PBV;           // bytes per LDS row
+    constexpr int PSTEP = PBV > 0 ? BM * PB : 64;      // byte distance between the planes of one operand
+    constexpr int PLANE = PBV > 0 ? BM * PB : BM * PB / 3;      // so that 3 * PLANE = one operand's bytes
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -151,15 +154,16 @@ __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             bf16x4 h, m, l;
-            const int off = (ar + 32 * i) * PB + kc * 8;
+            const int srow = ar + 32 * i;
+            const int off = SWZ ? srow * 64 + ((((kc >> 1) ^ ((srow >> 1) + (srow >> 3))) & 3) << 4) + (kc & 1) * 8 : srow * PB + kc * 8;
             if (ABL == 1) { for (int e = 0; e < 4; ++e) h[e] = (__bf16)ra[i][e]; m = h; l = h; } else split3(ra[i], h, m, l);
             *reinterpret_cast<bf16x4*>(As + off) = h;
-            *reinterpret_cast<bf16x4*>(As + PLANE + off) = m;
-            if (PRODS == 6) *reinterpret_cast<bf16x4*>(As + 2 * PLANE + off) = l;
+            *reinterpret_cast<bf16x4*>(As + PSTEP + off) = m;
+            if (PRODS == 6) *reinterpret_cast<bf16x4*>(As + 2 * PSTEP + off) = l;
             if (ABL == 1) { for (int e = 0; e < 4; ++e) h[e] = (__bf16)rb[i][e]; m = h; l = h; } else split3(rb[i], h, m, l);
             *reinterpret_cast<bf16x4*>(Bs + off) = h;
-            *reinterpret_cast<bf16x4*>(Bs + PLANE + off) = m;
-            if (PRODS == 6) *reinterpret_cast<bf16x4*>(Bs + 2 * PLANE + off) = l;
+            *reinterpret_cast<bf16x4*>(Bs + PSTEP + off) = m;
+            if (PRODS == 6) *reinterpret_cast<bf16x4*>(Bs + 2 * PSTEP + off) = l;
         }
     };
     const int frow = lane & 31, fk = (lane >> 5) * 16;       // byte offset of this lane's 8 bf16 inside a 16-deep k slab
@@ -174,12 +178,14 @@ __global__ __launch_bounds__(256, MINW) void gemm_split_kernel(const float* __re
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    a[i][p] = *reinterpret_cast<const bf16x8*>(As + p * PLANE + ((wm * 2 + i) * 32 + frow) * PB + kk * 32 + fk);
+                    a[i][p] = *reinterpret_cast<const bf16x8*>(As + p * PSTEP + (SWZ ? ((wm * 2 + i) * 32 + frow) * 64 + ((((kk * 2 + (lane >> 5)) ^ ((frow >> 1) + (frow >> 3))) & 3) << 4)
+                                                                                      : ((wm * 2 + i) * 32 + frow) * PB + kk * 32 + fk));
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    b[j][p] = *reinterpret_cast<const bf16x8*>(Bs + p * PLANE + ((wn * 2 + j) * 32 + frow) * PB + kk * 32 + fk);
+                    b[j][p] = *reinterpret_cast<const bf16x8*>(Bs + p * PSTEP + (SWZ ? ((wn * 2 + j) * 32 + frow) * 64 + ((((kk * 2 + (lane >> 5)) ^ ((frow >> 1) + (frow >> 3))) & 3) << 4)
+                                                                                      : ((wn * 2 + j) * 32 + frow) * PB + kk * 32 + fk));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -453,6 +459,11 @@ int main() {
         RUN("S6x2 ablation: no LDS stores / barriers in the loop", (gemm_split_kernel<2, 2, 6, 2>), 6 * 128 * 80);
         RUN("S6x2 ablation: MFMA only", (gemm_split_kernel<2, 2, 6, 3>), 6 * 128 * 80);
         RUN("S6x2 double-buffered LDS, one barrier per tile (1 WG/CU)", (gemm_split_kernel<1, 2, 6, 4>), 2 * 6 * 128 * 80);
+        RUN("S6x2 64-byte rows, chunk index swizzled by the row", (gemm_split_kernel<2, 2, 6, 0, 64>), 6 * 128 * 64);
+        RUN("S6x2 64-byte rows swizzled, (256,3)", (gemm_split_kernel<3, 2, 6, 0, 64>), 6 * 128 * 64);
+        RUN("S6x2 row pitch  96 B", (gemm_split_kernel<2, 2, 6, 0, 96>), 6 * 128 * 96);
+        RUN("S6x2 row pitch 112 B", (gemm_split_kernel<2, 2, 6, 0, 112>), 6 * 128 * 112);
+        RUN("S6x2 row pitch 144 B (1 WG/CU by LDS)", (gemm_split_kernel<2, 2, 6, 0, 144>), 6 * 128 * 144);
         RUN("P    K tiles of 16, double-buffered, staging between MFMA groups (pinned)", (gemm_pipe_kernel<2, true>), 2 * 6 * 128 * 48);
         RUN("P    same, compiler's own order", (gemm_pipe_kernel<2, false>), 2 * 6 * 128 * 48);
         CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(Ref)); CK(hipFree(err));
