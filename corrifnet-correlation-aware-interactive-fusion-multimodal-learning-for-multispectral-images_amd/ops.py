@@ -100,7 +100,7 @@ STREAM_K_LONG = False     # measured (round 2): wall-neutral on the B=32 step (2
 # no longer be bit-identical to the per-modality one.  Off: the two encoder schedules produce the same bits (tests/test_model_gpu.py).
 STREAM_K_GROUPED = False
 # Main loop of the GEMM family's 128-row tiles (CorrifGemm.f32_mfma / CorrifWgrad.f32_mfma = 0): fp32 operands split exactly into three
-# bf16 terms at the LDS store, six bf16 MFMA products per fp32 product, fp32 accumulation (csrc/igemm.hip "SPLIT").  Against fp64 the
+# bf16 terms at the LDS store, six bf16 MFMA products per fp32 product, fp32 accumulation (csrc/igemm_fwd.h "SPLIT").  Against fp64 the
 # result is MORE accurate than the fp32-input MFMA chain it replaces (one rounding per 16 products of the K sum instead of 16: 0.36x the
 # error at K = 2304-4608, tools/split_lab.hip) and 1.4-1.5x faster.  False = v_mfma_f32_32x32x2_f32 everywhere (rounds 1-3; A/B).
 SPLIT_BF16 = True

@@ -121,7 +121,7 @@ typedef struct CorrifGemm {
     /* Main loop of the 128-row tiles (the encoder's shapes): by default every fp32 operand is split exactly into three bf16 terms while it
      * is staged and the product is formed from six bf16 MFMA products with fp32 accumulation ("bf16x6": dropped terms <= 2^-25 |xy|; one
      * fp32 rounding per 16 products of the K sum - 0.36x the error of the fp32-input MFMA chain against fp64 at K = 2304-4608, and
-     * 1.4-1.5x its speed; csrc/igemm.hip, tools/split_lab.hip).  f32_mfma = 1 selects the v_mfma_f32_32x32x2_f32 loop instead (A/B). */
+     * 1.4-1.5x its speed; csrc/igemm_fwd.h, tools/split_lab.hip).  f32_mfma = 1 selects the v_mfma_f32_32x32x2_f32 loop instead (A/B). */
     int32_t f32_mfma;
 } CorrifGemm;
 int corrif_gemm_fwd(const CorrifGemm* p, void* stream);

@@ -296,7 +296,7 @@ def test_grouped_batch_norm_equals_its_twins(ops, relu_in, relu_out, res, C, tra
 
 def test_split_bf16_main_loop_is_at_least_as_accurate_as_the_fp32_mfma_chain(ops, monkeypatch):
     """ops.SPLIT_BF16 (default): the 128-row tiles form every fp32 product from six bf16 MFMA products of exactly split operands
-    (csrc/igemm.hip SPLIT).  A long-K convolution on the 128x128 tile (3x3x3... 1x3x3, 128 channels, 25088 rows: K = 1152) and a 1x1 with
+    (csrc/igemm_fwd.h SPLIT).  A long-K convolution on the 128x128 tile (1x3x3, 128 channels, 25088 rows: K = 1152) and a 1x1 with
     K = 2048 against fp64: the split loop must be inside the per-kernel bar and no worse than the v_mfma_f32_32x32x2_f32 chain it replaces
     (measured 0.4-0.8x its error: one fp32 rounding per 16 products of the K sum instead of 16), forward, data gradient and weight gradient."""
     cases = [(128, 128, (1, 3, 3), (0, 1, 1), (2, 4, 56, 56)), (2048, 256, (1, 1, 1), (0, 0, 0), (2, 4, 56, 56))]
